@@ -1,0 +1,186 @@
+/*
+ * sim3opt.h -- C-ABI of libsim3opt: MI355X-native Sim(3) pose-graph LM optimiser.
+ *
+ * Drop-in boundary for the path  optimizer.initializeOptimization();
+ * optimizer.optimize(100);  of the reference (kitti_surf.cpp:674-675, :1044-1045)
+ * on graphs of vio::VertexSim3Expmap / vio::EdgeSim3.  Each entry point names the
+ * g2o call of the reference it replaces.  Plain pointers and sizes only; the
+ * library copies everything it is given (the caller keeps no pointers into it).
+ *
+ * Conventions crossing the boundary:
+ *   Sim3 state      8 doubles [qx qy qz qw tx ty tz s]   (Eigen coeffs() order, kitti_surf.cpp:698)
+ *   tangent order   [omega(3), upsilon(3), sigma]        (g2o)
+ *   information     7x7 double, column-major, NULL = identity (kitti_surf.cpp:592, :637, :667)
+ *   vertex ids      arbitrary int32 (g2o allows any), mapped internally
+ *   errors          int status codes, no exceptions, no abort(); text via sim3opt_last_error
+ *
+ * All computation runs on the GPU (HIP, gfx950).  There is no CPU fallback: if no
+ * HIP device is usable, sim3opt_initialize returns SIM3OPT_ERR_NO_DEVICE.
+ */
+#ifndef SIM3OPT_H
+#define SIM3OPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sim3opt_graph sim3opt_graph;
+
+enum {
+  SIM3OPT_OK = 0,
+  SIM3OPT_ERR_ARG = -1,        /* bad argument (null, unknown id, duplicate id, ...) */
+  SIM3OPT_ERR_STATE = -2,      /* call order (e.g. optimize before initialize)       */
+  SIM3OPT_ERR_NO_DEVICE = -3,  /* no usable HIP device                               */
+  SIM3OPT_ERR_HIP = -4,        /* a HIP runtime call failed                          */
+  SIM3OPT_ERR_IO = -5,         /* file could not be read / parsed                    */
+  SIM3OPT_ERR_COMM = -6        /* RCCL communicator failure                          */
+};
+
+enum { SIM3OPT_KERNEL_NONE = 0, SIM3OPT_KERNEL_HUBER = 1 };
+enum { SIM3OPT_JAC_NUMERIC = 0, SIM3OPT_JAC_ANALYTIC = 1 };
+
+/* Solver configuration.  Replaces the reference's
+ *   OptimizationAlgorithmLevenberg(BlockSolverX(LinearSolverEigen))   kitti_surf.cpp:552-558
+ * and g2o's setUserLambdaInit / setMaxTrialsAfterFailure            kittiDetector.h:730, 779-782.
+ * Defaults (sim3opt_options_default) are g2o's. */
+typedef struct sim3opt_options {
+  double tau;               /* 1e-5  lambda0 = tau * max|H_dd|                           */
+  double user_lambda_init;  /* 0     > 0 overrides the tau rule                          */
+  double good_step_lower;   /* 1/3                                                       */
+  double good_step_upper;   /* 2/3                                                       */
+  int32_t max_trials;       /* 10    maxTrialsAfterFailure                               */
+  int32_t jacobian_mode;    /* SIM3OPT_JAC_NUMERIC (g2o default for EdgeSim3)            */
+  double fd_delta;          /* 1e-9  central-difference step of the numeric mode         */
+  double exp_eps;           /* 1e-5  branch threshold of exp/log (sim3_rv.h:133)         */
+  int32_t small_rot_half;   /* 0     R = I+W+W^2 (sim3_rv.h:151); 1: I+W+W^2/2           */
+  int32_t fix_small_angle_b;/* 0     B coefficient as written in sim3_rv.h:166/:290 (reference
+                                        behaviour); 1: exact small-theta limit               */
+  int32_t pcg_max_iters;    /* 0 = automatic (7 * free vertices, capped)                 */
+  double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
+  int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
+  int32_t device;           /* -1    HIP device ordinal; -1 = current device             */
+  int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */
+  int32_t time_kernels;     /* 0     1: bracket every SpMV / linearise launch with HIP events
+                                        (sim3opt_get_kernel_times); small launch-gap cost    */
+} sim3opt_options;
+
+/* Per-iteration record (g2o G2OBatchStatistics role; bal_example.cpp:55-56). */
+typedef struct sim3opt_iter_stats {
+  double chi2_before;
+  double chi2_after;
+  double lambda;        /* after the iteration's policy update */
+  double rho;           /* last gain ratio                     */
+  int32_t trials;       /* LM trials used                      */
+  int32_t pcg_iters;    /* PCG iterations summed over trials   */
+  double pcg_rel_res;   /* last achieved relative residual     */
+  double ms_linearize;  /* device time, HIP events             */
+  double ms_solve;
+  double ms_update;     /* oplus + chi2 + scale                */
+} sim3opt_iter_stats;
+
+/* Device time of the dominant kernels accumulated since initialize / reset
+ * (HIP events on the library's own stream; used by bench.py's roofline). */
+typedef struct sim3opt_kernel_times {
+  double ms_spmv;      int64_t n_spmv;
+  double ms_pcg_vec;   int64_t n_pcg_vec;
+  double ms_linearize; int64_t n_linearize;
+  double ms_chi2;      int64_t n_chi2;
+  double ms_update;    int64_t n_update;
+} sim3opt_kernel_times;
+
+int sim3opt_version(void);
+void sim3opt_options_default(sim3opt_options* o);
+
+/* g2o::SparseOptimizer ctor + setAlgorithm                         kitti_surf.cpp:552-558 */
+sim3opt_graph* sim3opt_create(void);
+void sim3opt_destroy(sim3opt_graph* g);
+int sim3opt_set_options(sim3opt_graph* g, const sim3opt_options* o);
+int sim3opt_get_options(const sim3opt_graph* g, sim3opt_options* o);
+const char* sim3opt_last_error(const sim3opt_graph* g);
+
+/* new VertexSim3Expmap; setEstimate; setFixed; setId; addVertex    kitti_surf.cpp:602-620 */
+int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int32_t fixed);
+/* bulk form for graphs too large for per-element calls */
+int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids /*NULL: 0..n-1 appended*/,
+                         const double* states /*n x 8*/, const uint8_t* fixed /*NULL: none*/);
+
+/* new EdgeSim3; setVertex(0,v0); setVertex(1,v1); setMeasurement; information(); [setRobustKernel];
+ * addEdge                                                            kitti_surf.cpp:633-638, :663-668 */
+int sim3opt_add_edge(sim3opt_graph* g, int32_t id_v0, int32_t id_v1, const double meas[8],
+                     const double* info77 /*NULL = I7*/, int32_t kernel, double kernel_delta);
+int sim3opt_add_edges(sim3opt_graph* g, int32_t m, const int32_t* id_v0, const int32_t* id_v1,
+                      const double* meas /*m x 8*/, const double* info /*NULL or m x 49*/,
+                      int32_t kernel, double kernel_delta);
+
+int32_t sim3opt_num_vertices(const sim3opt_graph* g);
+int32_t sim3opt_num_edges(const sim3opt_graph* g);
+/* edges()[k]: endpoint ids and measurement of the k-th edge added   (g2o OptimizableGraph::edges) */
+int sim3opt_get_edge(const sim3opt_graph* g, int32_t k, int32_t* id_v0, int32_t* id_v1,
+                     double meas[8]);
+
+/* SparseOptimizer::initializeOptimization()                        kitti_surf.cpp:674
+ * Builds the index mapping and the block-CSR pattern, uploads the graph to HBM. */
+int sim3opt_initialize(sim3opt_graph* g);
+
+/* SparseOptimizer::optimize(n)                                     kitti_surf.cpp:675
+ * Returns iterations executed (>0), -1 if nothing to optimise, 0 on failure
+ * (g2o convention; details via sim3opt_last_error). */
+int sim3opt_optimize(sim3opt_graph* g, int32_t max_iters);
+
+/* vertex(id)->estimate()                                           kitti_surf.cpp:688-689 */
+int sim3opt_get_vertex(sim3opt_graph* g, int32_t id, double state[8]);
+/* vertex(id)->setEstimate() after construction (warm start)        kitti_surf.cpp:1037-1038 */
+int sim3opt_set_vertex(sim3opt_graph* g, int32_t id, const double state[8]);
+/* all estimates in insertion order */
+int sim3opt_get_vertices(sim3opt_graph* g, double* states /*n x 8*/);
+int sim3opt_set_vertices(sim3opt_graph* g, const double* states /*n x 8*/);
+
+/* computeActiveErrors(); activeRobustChi2()                        kittiDetector.h:786-787 */
+int sim3opt_chi2(sim3opt_graph* g, double* chi2);
+
+/* statistics of the last optimize() */
+int32_t sim3opt_num_iterations(const sim3opt_graph* g);
+int sim3opt_get_stats(const sim3opt_graph* g, int32_t iter, sim3opt_iter_stats* out);
+int sim3opt_get_kernel_times(sim3opt_graph* g, sim3opt_kernel_times* out);
+int sim3opt_reset_kernel_times(sim3opt_graph* g);
+
+/* ---- kernel-level access (parity tests against the CPU oracle, bench roofline) ---- */
+/* per-edge residuals e (m x 7), edge insertion order                EdgeSim3::computeError */
+int sim3opt_edge_errors(sim3opt_graph* g, double* e_out);
+/* runs the linearisation kernels once on the current estimates     BlockSolver::buildSystem */
+int sim3opt_linearize(sim3opt_graph* g);
+/* dimensions of the block-CSR system: free block rows, stored 7x7 blocks */
+int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks);
+/* copies the block-CSR Hessian (rowptr nb+1, colidx nnzb, values nnzb x 49 column-major per
+ * block) and b (7 nb) to the host; block row k = k-th free vertex in insertion order */
+int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
+                       double* b);
+/* solves (H + lambda I) x = b with the block-Jacobi PCG on the last linearisation */
+int sim3opt_solve(sim3opt_graph* g, double lambda, double* x /*7 nb*/, int32_t* iters,
+                  double* rel_res);
+/* times `reps` back-to-back launches of the block-CSR SpMV kernel; returns mean ms */
+int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
+
+/* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
+ * Call between create and initialize.  unique_id is the 128-byte ncclUniqueId produced by
+ * sim3opt_comm_unique_id on rank 0 and broadcast by the caller (torch.distributed / MPI). */
+int sim3opt_comm_unique_id(uint8_t id_out[128]);
+int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]);
+/* host-side partition plan (no GPU needed): first block row of each rank, size world+1 */
+int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
+                           int32_t* row_begin /*world+1*/);
+
+/* ---- reference-format I/O (host C++; the callers either side of the path) ---- */
+/* Builds the graph of testDirectSim3Optimization                   kitti_surf.cpp:562-670
+ * from <dir>/cc.txt, <dir>/framePoses.txt (or framePoses_kf.txt), <dir>/loopConstraints.txt. */
+int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one_constraint);
+/* Writes "kfid s tx ty tz qx qy qz qw" rows (S_wi of each estimate)  kitti_surf.cpp:678-701;
+ * precision: 17 significant digits (the reference prints 6). image_ids may be NULL. */
+int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIM3OPT_H */

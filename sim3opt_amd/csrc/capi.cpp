@@ -1,0 +1,375 @@
+// capi.cpp -- the C-ABI of libsim3opt (include/sim3opt.h): argument checking, the host graph
+// container and dispatch into the HIP engine.  No exceptions leave this file.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sim3opt.h"
+#include "engine.hpp"
+#include "graph.hpp"
+
+using namespace sim3opt;
+
+struct sim3opt_graph {
+  HostGraph host;
+  Structure structure;
+  sim3opt_options opt;
+  Engine* engine = nullptr;
+  bool initialized = false;
+  std::vector<sim3opt_iter_stats> stats;
+  std::string err;
+  CommInfo comm;
+  ~sim3opt_graph() {
+    if (engine) engine_destroy(engine);
+  }
+};
+
+namespace {
+
+int fail(sim3opt_graph* g, int code, const char* msg) {
+  if (g) g->err = msg;
+  return code;
+}
+
+bool state_ok(const double s[8]) {
+  for (int i = 0; i < 8; ++i)
+    if (!std::isfinite(s[i])) return false;
+  return s[7] > 0.0;
+}
+
+sim3::Sim3 to_sim3(const double s[8]) {
+  sim3::Sim3 r;
+  r.q[0] = s[0]; r.q[1] = s[1]; r.q[2] = s[2]; r.q[3] = s[3];
+  r.t[0] = s[4]; r.t[1] = s[5]; r.t[2] = s[6]; r.s = s[7];
+  return r;
+}
+
+void from_sim3(const sim3::Sim3& r, double s[8]) {
+  s[0] = r.q[0]; s[1] = r.q[1]; s[2] = r.q[2]; s[3] = r.q[3];
+  s[4] = r.t[0]; s[5] = r.t[1]; s[6] = r.t[2]; s[7] = r.s;
+}
+
+bool is_identity77(const double* m) {
+  for (int c = 0; c < 7; ++c)
+    for (int r = 0; r < 7; ++r)
+      if (m[7 * c + r] != (r == c ? 1.0 : 0.0)) return false;
+  return true;
+}
+
+// pulls the current estimates back into the host container (so get/set work either side of
+// initialize, like g2o's vertex objects)
+int sync_host_states(sim3opt_graph* g) {
+  if (!g->initialized) return SIM3OPT_OK;
+  return engine_get_states(g->engine, g->host.states.data(), g->err);
+}
+
+int add_edge_impl(sim3opt_graph* g, int32_t id0, int32_t id1, const double* meas,
+                  const double* info, int32_t kernel, double kdelta) {
+  auto a = g->host.id2idx.find(id0), b = g->host.id2idx.find(id1);
+  if (a == g->host.id2idx.end() || b == g->host.id2idx.end())
+    return fail(g, SIM3OPT_ERR_ARG, "add_edge: unknown vertex id");
+  if (a->second == b->second) return fail(g, SIM3OPT_ERR_ARG, "add_edge: identical endpoints");
+  if (!state_ok(meas)) return fail(g, SIM3OPT_ERR_ARG, "add_edge: non-finite measurement or scale <= 0");
+  if (kernel != SIM3OPT_KERNEL_NONE && kernel != SIM3OPT_KERNEL_HUBER)
+    return fail(g, SIM3OPT_ERR_ARG, "add_edge: unknown robust kernel");
+  if (kernel == SIM3OPT_KERNEL_HUBER && !(kdelta > 0.0))
+    return fail(g, SIM3OPT_ERR_ARG, "add_edge: Huber delta must be > 0");
+  HostGraph& h = g->host;
+  const size_t m = h.ev0.size();
+  const bool nonident = info && !is_identity77(info);
+  if (nonident && h.info.empty()) {  // first non-identity information: materialise I7 for earlier edges
+    h.info.assign(49 * m, 0.0);
+    for (size_t k = 0; k < m; ++k)
+      for (int d = 0; d < 7; ++d) h.info[49 * k + 8 * d] = 1.0;
+  }
+  if (!h.info.empty()) {
+    const size_t off = h.info.size();
+    h.info.resize(off + 49, 0.0);
+    if (info) std::memcpy(&h.info[off], info, sizeof(double) * 49);
+    else for (int d = 0; d < 7; ++d) h.info[off + 8 * d] = 1.0;
+  }
+  const bool has_k = kernel == SIM3OPT_KERNEL_HUBER;
+  if (has_k && h.kdelta.empty()) h.kdelta.assign(m, 0.0);
+  if (!h.kdelta.empty()) h.kdelta.push_back(has_k ? kdelta : 0.0);
+  h.ev0.push_back(a->second);
+  h.ev1.push_back(b->second);
+  h.meas.push_back(to_sim3(meas));
+  return SIM3OPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sim3opt_version(void) { return 100; }
+
+void sim3opt_options_default(sim3opt_options* o) {
+  if (!o) return;
+  o->tau = 1e-5;
+  o->user_lambda_init = 0.0;
+  o->good_step_lower = 1.0 / 3.0;
+  o->good_step_upper = 2.0 / 3.0;
+  o->max_trials = 10;
+  o->jacobian_mode = SIM3OPT_JAC_NUMERIC;
+  o->fd_delta = 1e-9;
+  o->exp_eps = 1e-5;
+  o->small_rot_half = 0;
+  o->fix_small_angle_b = 0;
+  o->pcg_max_iters = 0;
+  o->pcg_rel_tol = 1e-10;
+  o->pcg_check_every = 16;
+  o->device = -1;
+  o->verbose = 0;
+  o->time_kernels = 0;
+}
+
+sim3opt_graph* sim3opt_create(void) {
+  sim3opt_graph* g = new (std::nothrow) sim3opt_graph();
+  if (g) sim3opt_options_default(&g->opt);
+  return g;
+}
+
+void sim3opt_destroy(sim3opt_graph* g) { delete g; }
+
+int sim3opt_set_options(sim3opt_graph* g, const sim3opt_options* o) {
+  if (!g || !o) return fail(g, SIM3OPT_ERR_ARG, "set_options: null argument");
+  if (!(o->fd_delta > 0) || !(o->exp_eps > 0) || o->max_trials < 1 || !(o->pcg_rel_tol >= 0) ||
+      !(o->tau > 0) || o->pcg_check_every < 0)
+    return fail(g, SIM3OPT_ERR_ARG, "set_options: value out of range");
+  g->opt = *o;
+  if (g->engine) engine_set_options(g->engine, g->opt);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_get_options(const sim3opt_graph* g, sim3opt_options* o) {
+  if (!g || !o) return SIM3OPT_ERR_ARG;
+  *o = g->opt;
+  return SIM3OPT_OK;
+}
+
+const char* sim3opt_last_error(const sim3opt_graph* g) { return g ? g->err.c_str() : "null graph"; }
+
+int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int32_t fixed) {
+  if (!g || !state) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: null argument");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_vertex: graph already initialized");
+  if (!state_ok(state)) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: non-finite state or scale <= 0");
+  HostGraph& h = g->host;
+  if (!h.id2idx.emplace(id, (int32_t)h.vid.size()).second)
+    return fail(g, SIM3OPT_ERR_ARG, "add_vertex: duplicate id");  // g2o addVertex returns false
+  h.vid.push_back(id);
+  h.states.push_back(to_sim3(state));
+  h.fixed.push_back(fixed ? 1 : 0);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids, const double* states,
+                         const uint8_t* fixed) {
+  if (!g || n < 0 || (n > 0 && !states)) return fail(g, SIM3OPT_ERR_ARG, "add_vertices: bad argument");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_vertices: graph already initialized");
+  HostGraph& h = g->host;
+  h.vid.reserve(h.vid.size() + n);
+  h.states.reserve(h.states.size() + n);
+  h.fixed.reserve(h.fixed.size() + n);
+  h.id2idx.reserve(h.id2idx.size() + n);
+  const int32_t base = (int32_t)h.vid.size();
+  for (int32_t k = 0; k < n; ++k) {
+    const int rc = sim3opt_add_vertex(g, ids ? ids[k] : base + k, states + 8 * (size_t)k,
+                                      fixed ? fixed[k] : 0);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  return SIM3OPT_OK;
+}
+
+int sim3opt_add_edge(sim3opt_graph* g, int32_t id_v0, int32_t id_v1, const double meas[8],
+                     const double* info77, int32_t kernel, double kernel_delta) {
+  if (!g || !meas) return fail(g, SIM3OPT_ERR_ARG, "add_edge: null argument");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_edge: graph already initialized");
+  return add_edge_impl(g, id_v0, id_v1, meas, info77, kernel, kernel_delta);
+}
+
+int sim3opt_add_edges(sim3opt_graph* g, int32_t m, const int32_t* id_v0, const int32_t* id_v1,
+                      const double* meas, const double* info, int32_t kernel,
+                      double kernel_delta) {
+  if (!g || m < 0 || (m > 0 && (!id_v0 || !id_v1 || !meas)))
+    return fail(g, SIM3OPT_ERR_ARG, "add_edges: bad argument");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_edges: graph already initialized");
+  HostGraph& h = g->host;
+  h.ev0.reserve(h.ev0.size() + m);
+  h.ev1.reserve(h.ev1.size() + m);
+  h.meas.reserve(h.meas.size() + m);
+  for (int32_t k = 0; k < m; ++k) {
+    const int rc = add_edge_impl(g, id_v0[k], id_v1[k], meas + 8 * (size_t)k,
+                                 info ? info + 49 * (size_t)k : nullptr, kernel, kernel_delta);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  return SIM3OPT_OK;
+}
+
+int32_t sim3opt_num_vertices(const sim3opt_graph* g) { return g ? g->host.nv() : 0; }
+int32_t sim3opt_num_edges(const sim3opt_graph* g) { return g ? g->host.ne() : 0; }
+
+int sim3opt_get_edge(const sim3opt_graph* g, int32_t k, int32_t* id_v0, int32_t* id_v1,
+                     double meas[8]) {
+  if (!g || k < 0 || k >= g->host.ne()) return SIM3OPT_ERR_ARG;
+  if (id_v0) *id_v0 = g->host.vid[g->host.ev0[k]];
+  if (id_v1) *id_v1 = g->host.vid[g->host.ev1[k]];
+  if (meas) from_sim3(g->host.meas[k], meas);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_initialize(sim3opt_graph* g) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (g->initialized) {  // g2o allows re-initialisation: rebuild from the current estimates
+    int rc = sync_host_states(g);
+    if (rc) return rc;
+    engine_destroy(g->engine);
+    g->engine = nullptr;
+    g->initialized = false;
+  }
+  if (!build_structure(g->host, g->structure, g->err)) return SIM3OPT_ERR_STATE;
+  int status = SIM3OPT_OK;
+  g->engine = engine_create(g->host, g->structure, g->opt, g->err, status);
+  if (!g->engine) return status;
+  g->initialized = true;
+  return SIM3OPT_OK;
+}
+
+int sim3opt_optimize(sim3opt_graph* g, int32_t max_iters) {
+  if (!g) return 0;
+  if (!g->initialized) {
+    // g2o: optimize() on an uninitialised / empty problem returns -1
+    if (g->host.ne() == 0 || g->host.nv() == 0) { g->err = "optimize: nothing to optimise"; return -1; }
+    g->err = "optimize: call sim3opt_initialize first";
+    return 0;
+  }
+  if (max_iters <= 0) return 0;
+  const int rc = engine_optimize(g->engine, max_iters, g->stats, g->err);
+  return rc < 0 ? 0 : rc;
+}
+
+int sim3opt_get_vertex(sim3opt_graph* g, int32_t id, double state[8]) {
+  if (!g || !state) return fail(g, SIM3OPT_ERR_ARG, "get_vertex: null argument");
+  auto it = g->host.id2idx.find(id);
+  if (it == g->host.id2idx.end()) return fail(g, SIM3OPT_ERR_ARG, "get_vertex: unknown id");
+  int rc = sync_host_states(g);
+  if (rc) return rc;
+  from_sim3(g->host.states[it->second], state);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_set_vertex(sim3opt_graph* g, int32_t id, const double state[8]) {
+  if (!g || !state) return fail(g, SIM3OPT_ERR_ARG, "set_vertex: null argument");
+  auto it = g->host.id2idx.find(id);
+  if (it == g->host.id2idx.end()) return fail(g, SIM3OPT_ERR_ARG, "set_vertex: unknown id");
+  if (!state_ok(state)) return fail(g, SIM3OPT_ERR_ARG, "set_vertex: non-finite state or scale <= 0");
+  int rc = sync_host_states(g);
+  if (rc) return rc;
+  g->host.states[it->second] = to_sim3(state);
+  if (g->initialized) return engine_set_states(g->engine, g->host.states.data(), g->err);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_get_vertices(sim3opt_graph* g, double* states) {
+  if (!g || !states) return fail(g, SIM3OPT_ERR_ARG, "get_vertices: null argument");
+  int rc = sync_host_states(g);
+  if (rc) return rc;
+  for (size_t k = 0; k < g->host.states.size(); ++k) from_sim3(g->host.states[k], states + 8 * k);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_set_vertices(sim3opt_graph* g, const double* states) {
+  if (!g || !states) return fail(g, SIM3OPT_ERR_ARG, "set_vertices: null argument");
+  for (size_t k = 0; k < g->host.states.size(); ++k)
+    if (!state_ok(states + 8 * k)) return fail(g, SIM3OPT_ERR_ARG, "set_vertices: bad state");
+  for (size_t k = 0; k < g->host.states.size(); ++k) g->host.states[k] = to_sim3(states + 8 * k);
+  if (g->initialized) return engine_set_states(g->engine, g->host.states.data(), g->err);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_chi2(sim3opt_graph* g, double* chi2) {
+  if (!g || !chi2) return fail(g, SIM3OPT_ERR_ARG, "chi2: null argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "chi2: call sim3opt_initialize first");
+  return engine_chi2(g->engine, chi2, g->err);
+}
+
+int32_t sim3opt_num_iterations(const sim3opt_graph* g) { return g ? (int32_t)g->stats.size() : 0; }
+
+int sim3opt_get_stats(const sim3opt_graph* g, int32_t iter, sim3opt_iter_stats* out) {
+  if (!g || !out || iter < 0 || iter >= (int32_t)g->stats.size()) return SIM3OPT_ERR_ARG;
+  *out = g->stats[iter];
+  return SIM3OPT_OK;
+}
+
+int sim3opt_get_kernel_times(sim3opt_graph* g, sim3opt_kernel_times* out) {
+  if (!g || !out) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "kernel_times: not initialized");
+  return engine_kernel_times(g->engine, out, false);
+}
+
+int sim3opt_reset_kernel_times(sim3opt_graph* g) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "kernel_times: not initialized");
+  return engine_kernel_times(g->engine, nullptr, true);
+}
+
+int sim3opt_edge_errors(sim3opt_graph* g, double* e_out) {
+  if (!g || !e_out) return fail(g, SIM3OPT_ERR_ARG, "edge_errors: null argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "edge_errors: call sim3opt_initialize first");
+  return engine_edge_errors(g->engine, e_out, g->err);
+}
+
+int sim3opt_linearize(sim3opt_graph* g) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "linearize: call sim3opt_initialize first");
+  return engine_linearize(g->engine, g->err);
+}
+
+int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks) {
+  if (!g || !g->initialized) return SIM3OPT_ERR_STATE;
+  if (n_block_rows) *n_block_rows = g->structure.nb;
+  if (n_blocks) *n_blocks = g->structure.nnzb;
+  return SIM3OPT_OK;
+}
+
+int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
+                       double* b) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "get_system: call sim3opt_initialize first");
+  return engine_get_system(g->engine, rowptr, colidx, values, b, g->err);
+}
+
+int sim3opt_solve(sim3opt_graph* g, double lambda, double* x, int32_t* iters, double* rel_res) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "solve: call sim3opt_initialize first");
+  return engine_solve(g->engine, lambda, x, iters, rel_res, g->err);
+}
+
+int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean) {
+  if (!g || !ms_mean || reps < 1) return fail(g, SIM3OPT_ERR_ARG, "bench_spmv: bad argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv: call sim3opt_initialize first");
+  return engine_bench_spmv(g->engine, reps, ms_mean, g->err);
+}
+
+int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
+                           int32_t* row_begin) {
+  if (n_block_rows < 0 || !rowptr || world < 1 || !row_begin) return SIM3OPT_ERR_ARG;
+  partition_rows(n_block_rows, rowptr, world, row_begin);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_comm_unique_id(uint8_t id_out[128]) {
+  (void)id_out;
+  return SIM3OPT_ERR_COMM;  // multi-GPU transport: comm.cpp (not linked in this build)
+}
+
+int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]) {
+  (void)unique_id;
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (world == 1 && rank == 0) return SIM3OPT_OK;
+  return fail(g, SIM3OPT_ERR_COMM, "comm_init: RCCL transport not built");
+}
+
+}  // extern "C"

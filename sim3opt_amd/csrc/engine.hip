@@ -1,0 +1,1107 @@
+// engine.hip -- device-resident Levenberg-Marquardt on a Sim(3) pose graph, gfx950 (MI355X).
+//
+// What it replaces in the reference (all third-party g2o code reached from
+// optimizer.optimize(100), kitti_surf.cpp:675; restated per SURVEY.md 3.3 / App. C):
+//   EdgeSim3::computeError                     -> k_chi2, k_edge_errors, k_linearize_numeric
+//   BaseBinaryEdge::linearizeOplus (numeric)   -> k_linearize_numeric (lane = one +-delta evaluation)
+//   BaseBinaryEdge::constructQuadraticForm     -> k_linearize_numeric (Gram phase) + k_diag_reduce
+//   BlockSolverX::buildSystem / setLambda      -> block-CSR values in HBM; lambda folded into SpMV
+//   LinearSolverEigen::solve (SimplicialLDLT)  -> block-Jacobi PCG: k_jacobi, k_spmv, k_pcg_*
+//   VertexSim3Expmap::oplusImpl, push/pop      -> k_oplus + device-to-device backup copies
+//   OptimizationAlgorithmLevenberg::solve      -> Engine::optimize (host control, 3 scalars per trial)
+//
+// HBM layout (all FP64, indices int32):
+//   states   V x 8   AoS, 64 B per vertex (one gather = one half-line)
+//   meas     E x 8   AoS, 64 B per edge; ev0/ev1 SoA int32; info E x 49 only if some edge is not I7
+//   vals     nnzb x 49, column-major 7x7 blocks, block row = free vertex, diagonal block first
+//   scratch  (#incidences) x 35: per (edge, endpoint) upper triangle of J^T W J (28) and -J^T W e (7)
+//   PCG vectors x r z p q b: 7*nb each; Minv nb x 49 row-major
+// Assembly is atomic-free and reduction orders are fixed, so results are bitwise reproducible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace sim3opt {
+
+using sim3::Sim3;
+
+#define HIPCHK(call)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+      return SIM3OPT_ERR_HIP;                                               \
+    }                                                                       \
+  } while (0)
+
+constexpr int WG = 256;         // 4 wavefronts of 64
+constexpr int MAX_GRID = 1024;  // grid cap of the streaming kernels = number of reduction partials
+
+// Scalars that live in HBM so the PCG loop needs no host round trip per iteration.
+struct DevScalars {
+  double rz[2];    // r.z of the current / next PCG iteration (ping-pong by parity)
+  double rz0;      // r.z at PCG start
+  double chi2;     // sum of (robustified) edge chi2
+  double scale;    // x.(lambda x + b)
+  unsigned long long maxdiag_bits;  // max |H_dd| as raw bits (non-negative doubles order as integers)
+  int32_t iter;      // PCG iterations executed
+  int32_t max_iter;  // PCG iteration cap
+  int32_t done;      // PCG finished (converged, cap reached or breakdown)
+  int32_t fail;      // PCG breakdown (p.q <= 0 or non-finite) or non-SPD diagonal block
+  double tol2;       // squared relative tolerance on ||r||_Minv
+};
+
+// ------------------------------------------------------------------------------------------
+// reductions (fixed order => deterministic)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n, double* sh4) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += WG) acc += p[i];
+  return block_sum(acc, sh4);
+}
+
+__global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ partials, int n,
+                                                  double* __restrict__ out) {
+  __shared__ double sh[4];
+  const double s = sum_partials(partials, n, sh);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-edge residual kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ Sim3 load_sim3(const Sim3* __restrict__ p) {
+  Sim3 s;
+  const double* d = reinterpret_cast<const double*>(p);
+  s.q[0] = d[0]; s.q[1] = d[1]; s.q[2] = d[2]; s.q[3] = d[3];
+  s.t[0] = d[4]; s.t[1] = d[5]; s.t[2] = d[6]; s.s = d[7];
+  return s;
+}
+
+__device__ __forceinline__ double quad_form(const double e[7], const double* __restrict__ Om) {
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    double col = 0.0;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) col += e[r] * Om[7 * c + r];
+    acc += col * e[c];
+  }
+  return acc;
+}
+
+// g2o RobustKernelHuber: rho(e2) and rho'(e2)
+__device__ __forceinline__ void huber(double e2, double delta, double& rho, double& w) {
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) {
+    rho = e2;
+    w = 1.0;
+  } else {
+    const double sq = sqrt(e2);
+    rho = 2 * sq * delta - dsqr;
+    w = delta / sq;
+  }
+}
+
+struct EdgeArgs {
+  int32_t ne;
+  const int32_t* ev0;
+  const int32_t* ev1;
+  const Sim3* meas;
+  const double* info;    // nullptr: identity
+  const double* kdelta;  // nullptr: no robust kernel
+  const Sim3* states;
+  sim3::Opts opts;
+};
+
+// computeActiveErrors + activeRobustChi2: one lane per edge, block partials in fixed order.
+__global__ __launch_bounds__(WG) void k_chi2(EdgeArgs A, double* __restrict__ partials) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int k = blockIdx.x * WG + threadIdx.x; k < A.ne; k += gridDim.x * WG) {
+    const Sim3 C = load_sim3(A.meas + k);
+    const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
+    const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
+    double e[7];
+    sim3::edge_error(C, S0, S1, A.opts, e);
+    double chi;
+    if (A.info) {
+      chi = quad_form(e, A.info + (size_t)49 * k);
+    } else {
+      chi = 0.0;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) chi += e[r] * e[r];
+    }
+    if (A.kdelta && A.kdelta[k] > 0.0) {
+      double rho, w;
+      huber(chi, A.kdelta[k], rho, w);
+      chi = rho;
+    }
+    acc += chi;
+  }
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(WG) void k_edge_errors(EdgeArgs A, double* __restrict__ out) {
+  for (int k = blockIdx.x * WG + threadIdx.x; k < A.ne; k += gridDim.x * WG) {
+    const Sim3 C = load_sim3(A.meas + k);
+    const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
+    const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
+    double e[7];
+    sim3::edge_error(C, S0, S1, A.opts, e);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) out[(size_t)7 * k + r] = e[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// linearisation, numeric Jacobians (g2o default for EdgeSim3)
+//   half-wavefront (32 lanes) per edge, 8 edges per 256-thread workgroup:
+//     lanes 0-13 : e(exp(+-delta e_d) S0, S1), d = lane/2        -> columns of A
+//     lanes 14-27: e(S0, exp(+-delta e_d) S1)                     -> columns of B
+//     lane 28    : unperturbed e
+//   then the 14x14 Gram matrix J^T W J and -J^T W e are formed from LDS and written with plain
+//   stores: off-diagonal 7x7 blocks straight into the block-CSR values (this edge owns them),
+//   diagonal contributions into the per-incidence scratch reduced by k_diag_reduce.
+// ------------------------------------------------------------------------------------------
+struct LinArgs {
+  int32_t n_active;
+  const int32_t* active;
+  const int32_t* ev0;
+  const int32_t* ev1;
+  const Sim3* meas;
+  const double* info;
+  const double* kdelta;
+  const Sim3* states;
+  const int32_t* slot01;
+  const int32_t* slot10;
+  const int32_t* inc0;
+  const int32_t* inc1;
+  double* vals;
+  double* scratch;
+  double delta;
+  sim3::Opts opts;
+};
+
+struct GramTables {
+  unsigned char ga[119], gb[119];  // Gram tasks: (a, b) with a <= b < 14, or b == 14 for J^T W e
+  unsigned char tr[28], tc[28];    // upper triangle (r <= c) in column-major order
+};
+__constant__ GramTables c_tab;
+
+constexpr int EPB = 8;  // edges per workgroup
+
+template <bool HAS_INFO, bool HAS_KERNEL>
+__global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
+  __shared__ double s_in[EPB][24];
+  __shared__ double s_J[EPB][15][7];                    // 14 Jacobian columns, column 14 = e
+  __shared__ double s_O[HAS_INFO ? EPB : 1][15][7];     // Omega * (J | e)
+  __shared__ double s_G[EPB][14][15];                   // upper Gram + column 14 = -J^T W e
+  const int l = threadIdx.x & 31, es = threadIdx.x >> 5;
+  const int ai = blockIdx.x * EPB + es;
+  const bool valid = ai < A.n_active;
+  int edge = 0;
+  if (valid) {
+    edge = A.active[ai];
+    // coalesced 64-B reads: measurement and the two vertex states, staged in LDS
+    if (l < 8) s_in[es][l] = reinterpret_cast<const double*>(A.meas + edge)[l];
+    else if (l < 16) s_in[es][l] = reinterpret_cast<const double*>(A.states + A.ev0[edge])[l - 8];
+    else if (l < 24) s_in[es][l] = reinterpret_cast<const double*>(A.states + A.ev1[edge])[l - 16];
+  }
+  __syncthreads();
+  double e[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (valid && l < 29) {
+    Sim3 C, S0, S1;
+    const double* in = s_in[es];
+    C.q[0] = in[0]; C.q[1] = in[1]; C.q[2] = in[2]; C.q[3] = in[3];
+    C.t[0] = in[4]; C.t[1] = in[5]; C.t[2] = in[6]; C.s = in[7];
+    S0.q[0] = in[8]; S0.q[1] = in[9]; S0.q[2] = in[10]; S0.q[3] = in[11];
+    S0.t[0] = in[12]; S0.t[1] = in[13]; S0.t[2] = in[14]; S0.s = in[15];
+    S1.q[0] = in[16]; S1.q[1] = in[17]; S1.q[2] = in[18]; S1.q[3] = in[19];
+    S1.t[0] = in[20]; S1.t[1] = in[21]; S1.t[2] = in[22]; S1.s = in[23];
+    if (l < 28) {
+      const int d = (l % 14) >> 1;
+      const double step = (l & 1) ? -A.delta : A.delta;
+      double xi[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xi[i] = (i == d) ? step : 0.0;
+      const Sim3 P = sim3::exp(xi, A.opts);
+      if (l < 14) S0 = sim3::mul(P, S0);
+      else S1 = sim3::mul(P, S1);
+    }
+    sim3::edge_error(C, S0, S1, A.opts, e);
+  }
+  const double scalar = 1.0 / (2.0 * A.delta);
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const double other = __shfl_down(e[r], 1);  // lane l+1 holds the -delta evaluation
+    if (valid && l < 28 && !(l & 1)) s_J[es][l >> 1][r] = scalar * (e[r] - other);
+    if (valid && l == 28) s_J[es][14][r] = e[r];
+  }
+  __syncthreads();
+  if (HAS_INFO) {
+    if (valid) {
+      const double* Om = A.info + (size_t)49 * edge;  // column-major
+      for (int t = l; t < 105; t += 32) {
+        const int a = t / 7, r = t % 7;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += Om[7 * k + r] * s_J[es][a][k];
+        s_O[es][a][r] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  double (*OJ)[7] = HAS_INFO ? s_O[es] : s_J[es];
+  double w = 1.0;
+  if (HAS_KERNEL) {
+    if (valid && A.kdelta[edge] > 0.0) {
+      double chi = 0.0, rho;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) chi += s_J[es][14][r] * OJ[14][r];
+      huber(chi, A.kdelta[edge], rho, w);
+    }
+  }
+  if (valid) {
+    for (int t = l; t < 119; t += 32) {
+      const int a = c_tab.ga[t], b = c_tab.gb[t];
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) acc += s_J[es][a][r] * OJ[b][r];
+      s_G[es][a][b] = (b == 14 ? -w : w) * acc;
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    const int s01 = A.slot01[edge], s10 = A.slot10[edge];
+    const int i0 = A.inc0[edge], i1 = A.inc1[edge];
+    double (*G)[15] = s_G[es];
+    for (int o = l; o < 168; o += 32) {
+      if (o < 49) {  // H01 = A^T W B, column-major
+        if (s01 >= 0) A.vals[(size_t)49 * s01 + o] = G[o % 7][7 + o / 7];
+      } else if (o < 98) {  // H10 = H01^T
+        const int p = o - 49;
+        if (s10 >= 0) A.vals[(size_t)49 * s10 + p] = G[p / 7][7 + p % 7];
+      } else if (o < 133) {  // endpoint 0: upper(A^T W A), -A^T W e
+        const int t = o - 98;
+        if (i0 >= 0)
+          A.scratch[(size_t)35 * i0 + t] = t < 28 ? G[c_tab.tr[t]][c_tab.tc[t]] : G[t - 28][14];
+      } else {  // endpoint 1
+        const int t = o - 133;
+        if (i1 >= 0)
+          A.scratch[(size_t)35 * i1 + t] =
+              t < 28 ? G[7 + c_tab.tr[t]][7 + c_tab.tc[t]] : G[7 + t - 28][14];
+      }
+    }
+  }
+}
+
+// One wavefront per block row: sums the per-incidence contributions in edge order, writes the
+// full symmetric diagonal block and b, tracks max |H_dd| (computeLambdaInit).
+__global__ __launch_bounds__(WG) void k_diag_reduce(int nb, const int32_t* __restrict__ incptr,
+                                                    const int32_t* __restrict__ rowptr,
+                                                    const double* __restrict__ scratch,
+                                                    double* __restrict__ vals,
+                                                    double* __restrict__ b, DevScalars* sc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane % 7, c = lane / 7;
+  const int m = r < c ? r : c, M = r < c ? c : r;
+  const int tsrc = lane < 49 ? (M * (M + 1)) / 2 + m : 0;
+  const int bsrc = lane < 7 ? 28 + lane : 0;
+  double dmax = 0.0;
+  for (int row = blockIdx.x * 4 + wave; row < nb; row += gridDim.x * 4) {
+    const int k0 = incptr[row], k1 = incptr[row + 1];
+    double sum = 0.0;
+    if (lane < 35)
+      for (int k = k0; k < k1; ++k) sum += scratch[(size_t)35 * k + lane];
+    const double v = __shfl(sum, tsrc);
+    const double bv = __shfl(sum, bsrc);
+    if (lane < 49) {
+      vals[(size_t)49 * rowptr[row] + lane] = v;
+      if (r == c) dmax = fmax(dmax, fabs(v));
+    }
+    if (lane < 7) b[(size_t)7 * row + lane] = bv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
+  if (lane == 0 && dmax > 0.0)
+    atomicMax(&sc->maxdiag_bits, (unsigned long long)__double_as_longlong(dmax));
+}
+
+// ------------------------------------------------------------------------------------------
+// block-Jacobi preconditioner: Minv = (H_ii + lambda I)^-1, one lane per block row
+// (Gauss-Jordan without pivoting; positive pivots <=> SPD block)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_jacobi(int nb, const int32_t* __restrict__ rowptr,
+                                               const double* __restrict__ vals, double lambda,
+                                               double* __restrict__ Minv, DevScalars* sc) {
+  const int row = blockIdx.x * WG + threadIdx.x;
+  if (row >= nb) return;
+  double a[7][7];
+  const double* src = vals + (size_t)49 * rowptr[row];
+#pragma unroll
+  for (int c = 0; c < 7; ++c)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) a[r][c] = src[7 * c + r];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) a[i][i] += lambda;
+  bool spd = true;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (!(a[k][k] > 0.0)) spd = false;
+    const double d = 1.0 / a[k][k];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j != k) a[k][j] *= d;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i != k) {
+        const double f = a[i][k];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+          if (j != k) a[i][j] -= f * a[k][j];
+        a[i][k] = -f * d;
+      }
+    a[k][k] = d;
+  }
+  if (!spd) sc->fail = 1;
+  double* dst = Minv + (size_t)49 * row;  // row-major
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[7 * r + c] = a[r][c];
+}
+
+// ------------------------------------------------------------------------------------------
+// PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
+// row's 7 entries sit in one wavefront (z = Minv r by shuffles) and addresses stay contiguous.
+// ------------------------------------------------------------------------------------------
+// q = (H + lambda I) p, partial p.q per workgroup.  One wavefront per block row, lane = one of
+// the 49 entries of the current 7x7 block; a row's blocks are one contiguous HBM stream.
+__global__ __launch_bounds__(WG) void k_spmv(int nb, const int32_t* __restrict__ rowptr,
+                                             const int32_t* __restrict__ colidx,
+                                             const double* __restrict__ vals,
+                                             const double* __restrict__ p,
+                                             double* __restrict__ q, double lambda,
+                                             double* __restrict__ partials,
+                                             const DevScalars* __restrict__ sc) {
+  __shared__ double sh[4];
+  if (sc && sc->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane % 7, c = lane / 7;
+  const bool act = lane < 49;
+  double pq = 0.0;
+  for (int row = blockIdx.x * 4 + wave; row < nb; row += gridDim.x * 4) {
+    const int k0 = rowptr[row], k1 = rowptr[row + 1];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+      const int col = colidx[k];
+      if (act) acc += vals[(size_t)49 * k + lane] * p[(size_t)7 * col + c];
+    }
+    double y = acc;
+#pragma unroll
+    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
+    if (lane < 7) {
+      const double pi = p[(size_t)7 * row + lane];
+      y += lambda * pi;
+      q[(size_t)7 * row + lane] = y;
+      pq += pi * y;
+    }
+  }
+  const double s = block_sum(pq, sh);
+  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
+}
+
+// x = 0, r = b, z = Minv b, p = z, partial r.z
+__global__ __launch_bounds__(WG) void k_pcg_init(int nb, const double* __restrict__ b,
+                                                 const double* __restrict__ Minv,
+                                                 double* __restrict__ x, double* __restrict__ r,
+                                                 double* __restrict__ z, double* __restrict__ p,
+                                                 double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane / 7, rr = lane % 7, base = lane - rr;
+  double rz = 0.0;
+  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
+    const int row = row0 + sub;
+    const bool act = lane < 63 && row < nb;
+    const size_t j = (size_t)7 * row + rr;
+    const double rv = act ? b[j] : 0.0;
+    double zv = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc) {
+      const double rc = __shfl(rv, base + cc);
+      if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
+    }
+    if (act) {
+      x[j] = 0.0;
+      r[j] = rv;
+      z[j] = zv;
+      p[j] = zv;
+      rz += rv * zv;
+    }
+  }
+  const double s = block_sum(rz, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void k_pcg_init_final(const double* __restrict__ partials, int n, DevScalars* sc,
+                                 int max_iter, double tol2) {
+  __shared__ double sh[4];
+  const double s = sum_partials(partials, n, sh);
+  if (threadIdx.x == 0) {
+    sc->rz[0] = s;
+    sc->rz[1] = 0.0;
+    sc->rz0 = s;
+    sc->iter = 0;
+    sc->max_iter = max_iter;
+    sc->tol2 = tol2;
+    sc->done = (s == 0.0 || !(s == s)) ? 1 : 0;
+    if (!(s == s) || s < 0.0) sc->fail = 1;
+  }
+}
+
+// alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z
+__global__ __launch_bounds__(WG) void k_pcg_update1(int nb, int par,
+                                                    const double* __restrict__ part_pq, int npart,
+                                                    const double* __restrict__ Minv,
+                                                    const double* __restrict__ p,
+                                                    const double* __restrict__ q,
+                                                    double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ z,
+                                                    double* __restrict__ part_rz, DevScalars* sc) {
+  __shared__ double sh[4];
+  if (sc->done) return;
+  const double pq = sum_partials(part_pq, npart, sh);
+  if (!(pq > 0.0) || !(pq < DBL_MAX)) {  // breakdown: not SPD or non-finite
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      sc->fail = 1;
+      sc->done = 1;
+    }
+    return;
+  }
+  const double alpha = sc->rz[par] / pq;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane / 7, rr = lane % 7, base = lane - rr;
+  double rz = 0.0;
+  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
+    const int row = row0 + sub;
+    const bool act = lane < 63 && row < nb;
+    const size_t j = (size_t)7 * row + rr;
+    double rv = 0.0;
+    if (act) {
+      x[j] += alpha * p[j];
+      rv = r[j] - alpha * q[j];
+      r[j] = rv;
+    }
+    double zv = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc) {
+      const double rc = __shfl(rv, base + cc);
+      if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
+    }
+    if (act) {
+      z[j] = zv;
+      rz += rv * zv;
+    }
+  }
+  const double s = block_sum(rz, sh);
+  if (threadIdx.x == 0) part_rz[blockIdx.x] = s;
+}
+
+// beta = rz_new / rz ; p = z + beta p ; workgroup 0 commits rz_new, the iteration count and the
+// stopping decision for the NEXT launches.
+__global__ __launch_bounds__(WG) void k_pcg_update2(int n, int par,
+                                                    const double* __restrict__ part_rz, int npart,
+                                                    const double* __restrict__ z,
+                                                    double* __restrict__ p, DevScalars* sc) {
+  __shared__ double sh[4];
+  if (sc->done) return;
+  const double rz_new = sum_partials(part_rz, npart, sh);
+  const double beta = rz_new / sc->rz[par];
+  for (int j = blockIdx.x * WG + threadIdx.x; j < n; j += gridDim.x * WG) p[j] = z[j] + beta * p[j];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->rz[par ^ 1] = rz_new;
+    const int it = sc->iter + 1;
+    sc->iter = it;
+    if (!(rz_new == rz_new)) {
+      sc->fail = 1;
+      sc->done = 1;
+    } else if (rz_new <= sc->tol2 * sc->rz0 || it >= sc->max_iter) {
+      sc->done = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// update and scale
+// ------------------------------------------------------------------------------------------
+// VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
+__global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
+                                              const double* __restrict__ x, Sim3* states,
+                                              sim3::Opts opts) {
+  const int v = blockIdx.x * WG + threadIdx.x;
+  if (v >= nv) return;
+  const int h = hidx[v];
+  if (h < 0) return;
+  double xi[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xi[i] = x[(size_t)7 * h + i];
+  const Sim3 P = sim3::exp(xi, opts);
+  const Sim3 S = sim3::mul(P, load_sim3(states + v));
+  double* d = reinterpret_cast<double*>(states + v);
+  d[0] = S.q[0]; d[1] = S.q[1]; d[2] = S.q[2]; d[3] = S.q[3];
+  d[4] = S.t[0]; d[5] = S.t[1]; d[6] = S.t[2]; d[7] = S.s;
+}
+
+// computeScale: sum_j x_j (lambda x_j + b_j)
+__global__ __launch_bounds__(WG) void k_scale(int n, const double* __restrict__ x,
+                                              const double* __restrict__ b, double lambda,
+                                              double* __restrict__ partials) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int j = blockIdx.x * WG + threadIdx.x; j < n; j += gridDim.x * WG)
+    acc += x[j] * (lambda * x[j] + b[j]);
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Engine
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t upload(T*& dptr, const std::vector<T>& h) {
+  const size_t bytes = sizeof(T) * std::max<size_t>(h.size(), 1);
+  hipError_t e = hipMalloc((void**)&dptr, bytes);
+  if (e != hipSuccess) return e;
+  if (!h.empty()) e = hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice);
+  return e;
+}
+
+static inline int grid_for(int64_t items, int per_block) {
+  const int64_t g = (items + per_block - 1) / per_block;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, MAX_GRID));
+}
+
+class Engine {
+ public:
+  sim3opt_options opt;
+  Structure st;  // host copy of the pattern
+  int32_t nv = 0, ne = 0, nb = 0, n = 0, n_active = 0;
+  int64_t nnzb = 0;
+  bool has_info = false, has_kernel = false;
+  hipStream_t stream = nullptr;
+  // graph
+  Sim3 *d_states = nullptr, *d_backup = nullptr, *d_meas = nullptr;
+  int32_t *d_ev0 = nullptr, *d_ev1 = nullptr, *d_hidx = nullptr, *d_active = nullptr;
+  double *d_info = nullptr, *d_kdelta = nullptr;
+  // system
+  int32_t *d_rowptr = nullptr, *d_colidx = nullptr, *d_incptr = nullptr;
+  int32_t *d_slot01 = nullptr, *d_slot10 = nullptr, *d_inc0 = nullptr, *d_inc1 = nullptr;
+  double *d_vals = nullptr, *d_scratch = nullptr, *d_b = nullptr, *d_Minv = nullptr;
+  double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
+  double *d_part_a = nullptr, *d_part_b = nullptr;
+  DevScalars* d_sc = nullptr;
+  DevScalars* h_sc = nullptr;  // pinned
+  bool linearized = false;
+  // timing
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  std::vector<hipEvent_t> pool;  // pairs (start, stop) for per-launch SpMV timing
+  size_t pool_used = 0;
+  sim3opt_kernel_times kt{};
+
+  ~Engine() { release(); }
+
+  void release() {
+    void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
+                    d_rowptr, d_colidx, d_incptr, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
+                    d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_part_a, d_part_b, d_sc};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    if (h_sc) (void)hipHostFree(h_sc);
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  sim3::Opts mopts() const { return sim3::Opts{opt.exp_eps, opt.small_rot_half, opt.fix_small_angle_b}; }
+
+  EdgeArgs edge_args() const {
+    return EdgeArgs{ne, d_ev0, d_ev1, d_meas, has_info ? d_info : nullptr,
+                    has_kernel ? d_kdelta : nullptr, d_states, mopts()};
+  }
+
+  int init(const HostGraph& g, const Structure& s, std::string& err) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      err = "no usable HIP device (libsim3opt has no CPU fallback)";
+      return SIM3OPT_ERR_NO_DEVICE;
+    }
+    if (opt.device >= 0) {
+      if (opt.device >= ndev) {
+        err = "device ordinal out of range";
+        return SIM3OPT_ERR_ARG;
+      }
+      HIPCHK(hipSetDevice(opt.device));
+    }
+    st = s;
+    nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
+    n_active = (int32_t)s.active.size();
+    has_info = !g.info.empty();
+    has_kernel = !g.kdelta.empty();
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ev_a));
+    HIPCHK(hipEventCreate(&ev_b));
+    HIPCHK(upload(d_states, g.states));
+    HIPCHK(hipMalloc((void**)&d_backup, sizeof(Sim3) * (size_t)nv));
+    HIPCHK(upload(d_meas, g.meas));
+    HIPCHK(upload(d_ev0, g.ev0));
+    HIPCHK(upload(d_ev1, g.ev1));
+    HIPCHK(upload(d_hidx, s.hidx));
+    HIPCHK(upload(d_active, s.active));
+    if (has_info) HIPCHK(upload(d_info, g.info));
+    if (has_kernel) HIPCHK(upload(d_kdelta, g.kdelta));
+    HIPCHK(upload(d_rowptr, s.rowptr));
+    HIPCHK(upload(d_colidx, s.colidx));
+    HIPCHK(upload(d_incptr, s.incptr));
+    HIPCHK(upload(d_slot01, s.slot01));
+    HIPCHK(upload(d_slot10, s.slot10));
+    HIPCHK(upload(d_inc0, s.inc0));
+    HIPCHK(upload(d_inc1, s.inc1));
+    HIPCHK(hipMalloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
+    HIPCHK(hipMemset(d_vals, 0, sizeof(double) * 49 * (size_t)nnzb));
+    const size_t ninc = (size_t)s.incptr[nb];
+    HIPCHK(hipMalloc((void**)&d_scratch, sizeof(double) * 35 * std::max<size_t>(ninc, 1)));
+    HIPCHK(hipMalloc((void**)&d_Minv, sizeof(double) * 49 * (size_t)nb));
+    double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q};
+    for (double** v : vecs) {
+      HIPCHK(hipMalloc((void**)v, sizeof(double) * (size_t)n));
+      HIPCHK(hipMemset(*v, 0, sizeof(double) * (size_t)n));
+    }
+    HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * MAX_GRID));
+    HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * MAX_GRID));
+    HIPCHK(hipMalloc((void**)&d_sc, sizeof(DevScalars)));
+    HIPCHK(hipMemset(d_sc, 0, sizeof(DevScalars)));
+    HIPCHK(hipHostMalloc((void**)&h_sc, sizeof(DevScalars)));
+    // Gram task tables
+    GramTables tab;
+    int t = 0;
+    for (int a = 0; a < 14; ++a)
+      for (int b = a; b < 15; ++b) { tab.ga[t] = (unsigned char)a; tab.gb[t] = (unsigned char)b; ++t; }
+    t = 0;
+    for (int c = 0; c < 7; ++c)
+      for (int r = 0; r <= c; ++r) { tab.tr[t] = (unsigned char)r; tab.tc[t] = (unsigned char)c; ++t; }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tab, sizeof(tab)));
+    HIPCHK(hipDeviceSynchronize());
+    return SIM3OPT_OK;
+  }
+
+  int fetch_scalars(std::string& err) {
+    HIPCHK(hipMemcpyAsync(h_sc, d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return SIM3OPT_OK;
+  }
+
+  // ---- timing helpers ----
+  int timed_begin(std::string& err) {
+    HIPCHK(hipEventRecord(ev_a, stream));
+    return SIM3OPT_OK;
+  }
+  int timed_end(double& ms_acc, std::string& err) {
+    HIPCHK(hipEventRecord(ev_b, stream));
+    HIPCHK(hipEventSynchronize(ev_b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev_a, ev_b));
+    ms_acc += ms;
+    return SIM3OPT_OK;
+  }
+  int pool_get(hipEvent_t& a, hipEvent_t& b, std::string& err) {
+    if (pool_used + 2 > pool.size()) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      pool.push_back(e0);
+      pool.push_back(e1);
+    }
+    a = pool[pool_used];
+    b = pool[pool_used + 1];
+    pool_used += 2;
+    return SIM3OPT_OK;
+  }
+  // after a stream sync: fold the recorded SpMV event pairs into the accumulators
+  int pool_drain(std::string& err) {
+    for (size_t i = 0; i + 1 < pool_used; i += 2) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, pool[i], pool[i + 1]));
+      kt.ms_spmv += ms;
+      kt.n_spmv += 1;
+    }
+    pool_used = 0;
+    return SIM3OPT_OK;
+  }
+
+  // ---- building blocks ----
+  int chi2(double* out, std::string& err) {
+    const int g = grid_for(ne, WG);
+    hipLaunchKernelGGL(k_chi2, dim3(g), dim3(WG), 0, stream, edge_args(), d_part_a);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
+    HIPCHK(hipGetLastError());
+    int rc = fetch_scalars(err);
+    if (rc) return rc;
+    *out = h_sc->chi2;
+    kt.n_chi2 += 1;
+    return SIM3OPT_OK;
+  }
+
+  int linearize(std::string& err) {
+    if (opt.jacobian_mode != SIM3OPT_JAC_NUMERIC) {
+      err = "jacobian_mode: only SIM3OPT_JAC_NUMERIC is implemented";
+      return SIM3OPT_ERR_ARG;
+    }
+    HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
+    LinArgs A{n_active, d_active, d_ev0, d_ev1, d_meas, d_info, d_kdelta, d_states,
+              d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts()};
+    const int g = (n_active + EPB - 1) / EPB;
+    if (g > 0) {
+      if (has_info && has_kernel)
+        hipLaunchKernelGGL((k_linearize_numeric<true, true>), dim3(g), dim3(WG), 0, stream, A);
+      else if (has_info)
+        hipLaunchKernelGGL((k_linearize_numeric<true, false>), dim3(g), dim3(WG), 0, stream, A);
+      else if (has_kernel)
+        hipLaunchKernelGGL((k_linearize_numeric<false, true>), dim3(g), dim3(WG), 0, stream, A);
+      else
+        hipLaunchKernelGGL((k_linearize_numeric<false, false>), dim3(g), dim3(WG), 0, stream, A);
+    }
+    hipLaunchKernelGGL(k_diag_reduce, dim3(grid_for(nb, 4)), dim3(WG), 0, stream, nb, d_incptr,
+                       d_rowptr, d_scratch, d_vals, d_b, d_sc);
+    HIPCHK(hipGetLastError());
+    linearized = true;
+    kt.n_linearize += 1;
+    return SIM3OPT_OK;
+  }
+
+  int spmv_launch(double lambda, bool in_pcg, std::string& err) {
+    const int g = grid_for(nb, 4);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (opt.time_kernels) {
+      int rc = pool_get(a, b, err);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(a, stream));
+    }
+    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, stream, nb, d_rowptr, d_colidx, d_vals, d_p,
+                       d_q, lambda, d_part_a, in_pcg ? d_sc : nullptr);
+    if (opt.time_kernels) HIPCHK(hipEventRecord(b, stream));
+    return SIM3OPT_OK;
+  }
+
+  // block-Jacobi PCG on (H + lambda I) x = b; result stays in d_x.
+  int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
+    const int gj = (nb + WG - 1) / WG;
+    const int gv = grid_for((nb + 8) / 9, 4);  // 36 block rows per workgroup pass
+    const int gs = grid_for(nb, 4);
+    const int ge = grid_for(n, WG);
+    int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 20000);
+    const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
+    HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, nb, d_rowptr, d_vals, lambda,
+                       d_Minv, d_sc);
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, nb, d_b, d_Minv, d_x, d_r, d_z,
+                       d_p, d_part_b);
+    hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(WG), 0, stream, d_part_b, gv, d_sc, max_it,
+                       tol2);
+    HIPCHK(hipGetLastError());
+    const int chunk = std::max(1, opt.pcg_check_every);
+    int it = 0, par = 0;
+    for (;;) {
+      int rc = fetch_scalars(err);
+      if (rc) return rc;
+      if (opt.time_kernels) {
+        rc = pool_drain(err);
+        if (rc) return rc;
+      }
+      if (h_sc->done || it >= max_it) break;
+      const int todo = std::min(chunk, max_it - it);
+      for (int c = 0; c < todo; ++c) {
+        rc = spmv_launch(lambda, true, err);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pcg_update1, dim3(gv), dim3(WG), 0, stream, nb, par, d_part_a, gs,
+                           d_Minv, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
+        hipLaunchKernelGGL(k_pcg_update2, dim3(ge), dim3(WG), 0, stream, n, par, d_part_b, gv,
+                           d_z, d_p, d_sc);
+        par ^= 1;
+        ++it;
+      }
+      HIPCHK(hipGetLastError());
+    }
+    kt.n_pcg_vec += h_sc->iter;
+    *iters = h_sc->iter;
+    const double rzf = h_sc->rz[h_sc->iter & 1];
+    *rel_res = h_sc->rz0 > 0 ? std::sqrt(std::fabs(rzf) / h_sc->rz0) : 0.0;
+    *ok = !h_sc->fail;
+    return SIM3OPT_OK;
+  }
+
+  int optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, std::string& err) {
+    stats.clear();
+    double lambda = 0.0, ni = 2.0;
+    bool ok = true;
+    int iters = 0;
+    for (int it = 0; it < max_iters && ok; ++it) {
+      sim3opt_iter_stats T{};
+      double currentChi = 0.0;
+      int rc = timed_begin(err);
+      if (rc) return rc;
+      rc = chi2(&currentChi, err);
+      if (rc) return rc;
+      double tempChi = currentChi;
+      T.chi2_before = currentChi;
+      rc = linearize(err);
+      if (rc) return rc;
+      rc = timed_end(T.ms_linearize, err);
+      if (rc) return rc;
+      kt.ms_linearize += T.ms_linearize;
+      if (it == 0) {
+        rc = fetch_scalars(err);
+        if (rc) return rc;
+        double maxdiag;
+        std::memcpy(&maxdiag, &h_sc->maxdiag_bits, sizeof(double));
+        lambda = opt.user_lambda_init > 0 ? opt.user_lambda_init : opt.tau * maxdiag;
+        ni = 2.0;
+      }
+      double rho = 0.0;
+      int qmax = 0;
+      do {
+        HIPCHK(hipMemcpyAsync(d_backup, d_states, sizeof(Sim3) * (size_t)nv,
+                              hipMemcpyDeviceToDevice, stream));  // push
+        rc = timed_begin(err);
+        if (rc) return rc;
+        int32_t pit = 0;
+        double rres = 0.0;
+        bool ok2 = true;
+        rc = pcg(lambda, &pit, &rres, &ok2, err);
+        if (rc) return rc;
+        rc = timed_end(T.ms_solve, err);
+        if (rc) return rc;
+        T.pcg_iters += pit;
+        T.pcg_rel_res = rres;
+        rc = timed_begin(err);
+        if (rc) return rc;
+        double scale = 0.0;
+        if (ok2) {
+          hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
+                             d_x, d_states, mopts());
+          const int ge = grid_for(n, WG);
+          hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, n, d_x, d_b, lambda,
+                             d_part_b);
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, ge,
+                             &d_sc->scale);
+          HIPCHK(hipGetLastError());
+          rc = chi2(&tempChi, err);  // also brings back scale
+          if (rc) return rc;
+          scale = h_sc->scale;
+          kt.n_update += 1;
+        } else {
+          tempChi = DBL_MAX;  // solver failed: g2o forces rejection
+        }
+        rho = currentChi - tempChi;
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+          alpha = std::min(alpha, opt.good_step_upper);
+          lambda *= std::max(opt.good_step_lower, alpha);
+          ni = 2.0;
+          currentChi = tempChi;  // discardTop
+        } else {
+          lambda *= ni;
+          ni *= 2.0;
+          HIPCHK(hipMemcpyAsync(d_states, d_backup, sizeof(Sim3) * (size_t)nv,
+                                hipMemcpyDeviceToDevice, stream));  // pop
+        }
+        rc = timed_end(T.ms_update, err);
+        if (rc) return rc;
+        ++qmax;
+      } while (rho < 0 && qmax < opt.max_trials);
+      kt.ms_update += T.ms_update;
+      T.chi2_after = currentChi;
+      T.lambda = lambda;
+      T.rho = rho;
+      T.trials = qmax;
+      stats.push_back(T);
+      ++iters;
+      if (opt.verbose)
+        std::fprintf(stderr,
+                     "iteration= %d\t chi2= %.9g\t lambda= %.6g\t levenbergIter= %d\t pcg= %d "
+                     "(rel %.2e)\t ms lin/solve/upd= %.3f/%.3f/%.3f\n",
+                     it, currentChi, lambda, qmax, T.pcg_iters, T.pcg_rel_res, T.ms_linearize,
+                     T.ms_solve, T.ms_update);
+      if (qmax == opt.max_trials || rho == 0 || !std::isfinite(lambda)) ok = false;  // Terminate
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return iters;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// C++ interface used by capi.cpp
+// ------------------------------------------------------------------------------------------
+Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_options& opt,
+                      std::string& err, int& status) {
+  Engine* e = new Engine();
+  e->opt = opt;
+  status = e->init(g, s, err);
+  if (status != SIM3OPT_OK) {
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+void engine_destroy(Engine* e) { delete e; }
+
+int engine_set_options(Engine* e, const sim3opt_options& opt) {
+  const int dev = e->opt.device;
+  e->opt = opt;
+  e->opt.device = dev;
+  return SIM3OPT_OK;
+}
+
+int engine_optimize(Engine* e, int32_t max_iters, std::vector<sim3opt_iter_stats>& stats,
+                    std::string& err) {
+  return e->optimize(max_iters, stats, err);
+}
+
+int engine_chi2(Engine* e, double* chi2, std::string& err) { return e->chi2(chi2, err); }
+
+int engine_get_states(Engine* e, Sim3* out, std::string& err) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, e->d_states, sizeof(Sim3) * (size_t)e->nv, hipMemcpyDeviceToHost));
+  return SIM3OPT_OK;
+}
+
+int engine_set_states(Engine* e, const Sim3* in, std::string& err) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->d_states, in, sizeof(Sim3) * (size_t)e->nv, hipMemcpyHostToDevice));
+  e->linearized = false;
+  return SIM3OPT_OK;
+}
+
+int engine_edge_errors(Engine* e, double* out, std::string& err) {
+  double* d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_out, sizeof(double) * 7 * std::max<size_t>((size_t)e->ne, 1)));
+  hipLaunchKernelGGL(k_edge_errors, dim3(grid_for(e->ne, WG)), dim3(WG), 0, e->stream,
+                     e->edge_args(), d_out);
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
+  if (le == hipSuccess)
+    le = hipMemcpy(out, d_out, sizeof(double) * 7 * (size_t)e->ne, hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if (le != hipSuccess) {
+    err = std::string("edge_errors: ") + hipGetErrorString(le);
+    return SIM3OPT_ERR_HIP;
+  }
+  return SIM3OPT_OK;
+}
+
+int engine_linearize(Engine* e, std::string& err) {
+  int rc = e->linearize(err);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SIM3OPT_OK;
+}
+
+int engine_get_system(Engine* e, int32_t* rowptr, int32_t* colidx, double* values, double* b,
+                      std::string& err) {
+  if (!e->linearized) {
+    err = "get_system: call sim3opt_linearize (or optimize) first";
+    return SIM3OPT_ERR_STATE;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (rowptr) std::memcpy(rowptr, e->st.rowptr.data(), sizeof(int32_t) * (size_t)(e->nb + 1));
+  if (colidx) std::memcpy(colidx, e->st.colidx.data(), sizeof(int32_t) * (size_t)e->nnzb);
+  if (values)
+    HIPCHK(hipMemcpy(values, e->d_vals, sizeof(double) * 49 * (size_t)e->nnzb,
+                     hipMemcpyDeviceToHost));
+  if (b) HIPCHK(hipMemcpy(b, e->d_b, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost));
+  return SIM3OPT_OK;
+}
+
+int engine_solve(Engine* e, double lambda, double* x, int32_t* iters, double* rel_res,
+                 std::string& err) {
+  if (!e->linearized) {
+    err = "solve: call sim3opt_linearize (or optimize) first";
+    return SIM3OPT_ERR_STATE;
+  }
+  int32_t it = 0;
+  double rr = 0.0;
+  bool ok = true;
+  int rc = e->pcg(lambda, &it, &rr, &ok, err);
+  if (rc) return rc;
+  if (iters) *iters = it;
+  if (rel_res) *rel_res = rr;
+  if (x) HIPCHK(hipMemcpy(x, e->d_x, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost));
+  if (!ok) {
+    err = "solve: PCG breakdown (system not positive definite)";
+    return SIM3OPT_ERR_STATE;
+  }
+  return SIM3OPT_OK;
+}
+
+int engine_bench_spmv(Engine* e, int32_t reps, double* ms_mean, std::string& err) {
+  if (!e->linearized) {
+    err = "bench_spmv: call sim3opt_linearize (or optimize) first";
+    return SIM3OPT_ERR_STATE;
+  }
+  const int g = grid_for(e->nb, 4);
+  // p = b as a representative dense vector
+  HIPCHK(hipMemcpyAsync(e->d_p, e->d_b, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToDevice,
+                        e->stream));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, e->stream, e->nb, e->d_rowptr, e->d_colidx,
+                       e->d_vals, e->d_p, e->d_q, 0.0, e->d_part_a, (const DevScalars*)nullptr);
+  HIPCHK(hipEventRecord(e->ev_a, e->stream));
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, e->stream, e->nb, e->d_rowptr, e->d_colidx,
+                       e->d_vals, e->d_p, e->d_q, 0.0, e->d_part_a, (const DevScalars*)nullptr);
+  HIPCHK(hipEventRecord(e->ev_b, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev_b));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev_a, e->ev_b));
+  *ms_mean = reps > 0 ? ms / reps : 0.0;
+  return SIM3OPT_OK;
+}
+
+int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {
+  if (out) *out = e->kt;
+  if (reset) e->kt = sim3opt_kernel_times{};
+  return SIM3OPT_OK;
+}
+
+}  // namespace sim3opt

@@ -1,0 +1,44 @@
+// engine.hpp -- device-resident Levenberg-Marquardt engine (interface).
+//
+// Replaces g2o's OptimizationAlgorithmLevenberg + BlockSolverX + LinearSolverEigen
+// (instantiated at kitti_surf.cpp:552-558) and the per-edge / per-vertex virtual calls
+// behind SparseOptimizer::optimize (kitti_surf.cpp:675).  Implementation: engine.hip.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sim3opt.h"
+#include "graph.hpp"
+
+namespace sim3opt {
+
+class Engine;  // opaque, defined in engine.hip
+
+Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_options& opt,
+                      std::string& err, int& status);
+void engine_destroy(Engine* e);
+
+// multi-GPU: attach an RCCL communicator before engine_create (comm.cpp)
+struct CommInfo {
+  int32_t rank = 0, world = 1;
+  void* nccl_comm = nullptr;  // ncclComm_t
+};
+
+int engine_set_options(Engine* e, const sim3opt_options& opt);
+int engine_optimize(Engine* e, int32_t max_iters, std::vector<sim3opt_iter_stats>& stats,
+                    std::string& err);
+int engine_chi2(Engine* e, double* chi2, std::string& err);
+int engine_get_states(Engine* e, sim3::Sim3* out, std::string& err);
+int engine_set_states(Engine* e, const sim3::Sim3* in, std::string& err);
+int engine_edge_errors(Engine* e, double* out, std::string& err);
+int engine_linearize(Engine* e, std::string& err);
+int engine_get_system(Engine* e, int32_t* rowptr, int32_t* colidx, double* values, double* b,
+                      std::string& err);
+int engine_solve(Engine* e, double lambda, double* x, int32_t* iters, double* rel_res,
+                 std::string& err);
+int engine_bench_spmv(Engine* e, int32_t reps, double* ms_mean, std::string& err);
+int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset);
+
+}  // namespace sim3opt

@@ -1,0 +1,65 @@
+// graph.hpp -- host-side pose-graph container and block-CSR structure builder.
+//
+// Replaces the container half of g2o::SparseOptimizer / OptimizableGraph /
+// HyperGraph (addVertex, addEdge, vertex(id), initializeOptimization's index
+// mapping; reference call sites kitti_surf.cpp:558, 620, 634-638, 664-668, 674).
+// Pure host C++17, no GPU calls: the structure it builds is what the HIP engine
+// uploads to HBM.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sim3_math.hpp"
+
+namespace sim3opt {
+
+struct HostGraph {
+  // vertices, insertion order
+  std::vector<int32_t> vid;
+  std::unordered_map<int32_t, int32_t> id2idx;
+  std::vector<sim3::Sim3> states;
+  std::vector<uint8_t> fixed;
+  // edges, insertion order; endpoints as vertex indices
+  std::vector<int32_t> ev0, ev1;
+  std::vector<sim3::Sim3> meas;
+  std::vector<double> info;    // empty while every edge has identity information, else m x 49
+  std::vector<double> kdelta;  // empty while no edge has a robust kernel, else m (0 = none, >0 = Huber)
+
+  int32_t nv() const { return (int32_t)vid.size(); }
+  int32_t ne() const { return (int32_t)ev0.size(); }
+};
+
+// Block-CSR pattern of the LM normal equations, full-symmetric storage, 7x7 blocks.
+//   block row k  = k-th free vertex in insertion order (g2o: hessianIndex; fixed -> -1)
+//   row layout   = [diagonal block, then one block per incident edge whose other endpoint is
+//                   free, sorted by (column, edge index)] -- parallel edges keep separate blocks,
+//                   so the linearisation kernel owns every off-diagonal block exclusively
+//                   (plain stores, no atomics) and SpMV sums them implicitly.
+//   incidence    = for each free vertex the list of (edge, role) pairs in edge order; the
+//                   linearisation kernel writes per-incidence diagonal/b contributions which a
+//                   row kernel reduces in that fixed order (deterministic assembly).
+struct Structure {
+  int32_t nb = 0;                  // free block rows
+  int64_t nnzb = 0;                // stored blocks
+  std::vector<int32_t> hidx;       // vertex index -> block row or -1
+  std::vector<int32_t> row2vertex; // block row -> vertex index
+  std::vector<int32_t> rowptr;     // nb + 1
+  std::vector<int32_t> colidx;     // nnzb
+  std::vector<int32_t> slot01;     // per edge: block index of H(h0,h1), -1 if not both free
+  std::vector<int32_t> slot10;     // per edge: block index of H(h1,h0)
+  std::vector<int32_t> incptr;     // nb + 1
+  std::vector<int32_t> inc0;       // per edge: incidence slot of endpoint 0, -1 if fixed
+  std::vector<int32_t> inc1;       // per edge: incidence slot of endpoint 1, -1 if fixed
+  std::vector<int32_t> active;     // edges with at least one free endpoint (linearised)
+};
+
+// Returns false and fills err on malformed graphs (no free vertex, no edge, ...).
+bool build_structure(const HostGraph& g, Structure& s, std::string& err);
+
+// Contiguous row partition balanced by stored blocks (multi-GPU row split); begin has world+1 entries.
+void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin);
+
+}  // namespace sim3opt

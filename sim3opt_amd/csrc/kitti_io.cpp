@@ -1,0 +1,173 @@
+// kitti_io.cpp -- reference-format loaders and the graph builder of the direct Sim3 PGO.
+//
+// Host C++ for the callers either side of the hot path:
+//   LoadKFIndices / LoadKFPoses ......... kitti_surf.cpp:232-292
+//   LoadLoopConstraints (Sim3) .......... kitti_surf.cpp:145-205
+//   roteu2ro ............................ kittiDetector.h:225-243
+//   graph of testDirectSim3Optimization . kitti_surf.cpp:575-670
+//   pose writer ......................... kitti_surf.cpp:678-701
+// Built on the public C-ABI only (sim3opt_add_vertex / sim3opt_add_edge).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/sim3opt.h"
+#include "sim3_math.hpp"
+
+namespace {
+
+using sim3::Sim3;
+
+void euler_rpy_to_R(double r, double p, double y, double R[9]) {  // Rz(yaw) Ry(pitch) Rx(roll)
+  const double cr = std::cos(r), sr = std::sin(r), cp = std::cos(p), sp = std::sin(p);
+  const double ch = std::cos(y), sh = std::sin(y);
+  R[0] = cp * ch; R[1] = sp * sr * ch - cr * sh; R[2] = cr * sp * ch + sh * sr;
+  R[3] = cp * sh; R[4] = sr * sp * sh + cr * ch; R[5] = cr * sp * sh - sr * ch;
+  R[6] = -sp;     R[7] = sr * cp;                R[8] = cr * cp;
+}
+
+bool read_lines(const std::string& path, std::vector<std::string>& out) {
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) return false;
+  std::string ln;
+  while (std::getline(f, ln)) {
+    if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+    out.push_back(ln);
+  }
+  return true;
+}
+
+bool blank(const std::string& s) { return s.find_first_not_of(" \t") == std::string::npos; }
+
+void to_array(const Sim3& s, double a[8]) {
+  a[0] = s.q[0]; a[1] = s.q[1]; a[2] = s.q[2]; a[3] = s.q[3];
+  a[4] = s.t[0]; a[5] = s.t[1]; a[6] = s.t[2]; a[7] = s.s;
+}
+
+}  // namespace
+
+extern "C" int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one) {
+  if (!g || !dir) return SIM3OPT_ERR_ARG;
+  const std::string d(dir);
+  // cc.txt: keyframe id = line number, image id = value (kitti_surf.cpp:232-254)
+  std::vector<int> cc;
+  {
+    std::ifstream f((d + "/cc.txt").c_str());
+    if (!f.is_open()) return SIM3OPT_ERR_IO;
+    int v;
+    while (f >> v) cc.push_back(v);
+  }
+  if (cc.empty()) return SIM3OPT_ERR_IO;
+  // framePoses: 2 header lines, "id, time, r, p, y, x, y, z" of T_c2w; keep ids in cc (:255-292)
+  std::vector<std::string> lines;
+  if (!read_lines(d + "/framePoses.txt", lines) && !read_lines(d + "/framePoses_kf.txt", lines))
+    return SIM3OPT_ERR_IO;
+  std::vector<Sim3> Siw(cc.size());
+  size_t it = 0;
+  for (size_t ln = 2; ln < lines.size() && it < cc.size(); ++ln) {
+    if (blank(lines[ln])) continue;
+    int id;
+    double tm, v[6];
+    if (std::sscanf(lines[ln].c_str(), "%d, %lf, %lf, %lf, %lf, %lf, %lf, %lf", &id, &tm, &v[0],
+                    &v[1], &v[2], &v[3], &v[4], &v[5]) != 8)
+      return SIM3OPT_ERR_IO;
+    if (id != cc[it]) continue;
+    double R[9], qc2w[4], Rw2c[9];
+    euler_rpy_to_R(v[0], v[1], v[2], R);
+    // Sophus::SE3d(Rc2w, t).inverse(): conjugate quaternion, t' = R^-1 (-t)      (:283-285)
+    sim3::quat_from_R(R, qc2w);
+    Sim3 s;
+    const double qw2c[4] = {-qc2w[0], -qc2w[1], -qc2w[2], qc2w[3]};
+    const double nt[3] = {-v[3], -v[4], -v[5]};
+    sim3::quat_rot(qw2c, nt, s.t);
+    // g2o::Sim3(Rcw, tcw, 1.0) with Rcw = Tw2c.rotationMatrix()                  (:606-608)
+    sim3::R_from_quat(qw2c, Rw2c);
+    sim3::quat_from_R(Rw2c, s.q);
+    s.s = 1.0;
+    Siw[it++] = s;
+  }
+  if (it != cc.size()) return SIM3OPT_ERR_IO;  // reference: assert(it == vpKFs.end())
+  // loopConstraints: 5 header lines, 4 lines per loop; ids from line 1, values from line 4 (:145-205)
+  lines.clear();
+  if (!read_lines(d + "/loopConstraints.txt", lines)) return SIM3OPT_ERR_IO;
+  struct Loop { int f1, f2; Sim3 C; };
+  std::vector<Loop> loops;
+  {
+    std::vector<std::string> rec;
+    for (size_t ln = 5; ln < lines.size(); ++ln)
+      if (!blank(lines[ln])) rec.push_back(lines[ln]);
+    for (size_t k = 0; k + 3 < rec.size(); k += 4) {
+      unsigned f1, f2;
+      double gt[6], v[6], sf2s;
+      int matches;
+      if (std::sscanf(rec[k].c_str(), "%u %u %lf %lf %lf %lf %lf %lf", &f1, &f2, &gt[0], &gt[1],
+                      &gt[2], &gt[3], &gt[4], &gt[5]) != 8)
+        return SIM3OPT_ERR_IO;
+      if (std::sscanf(rec[k + 3].c_str(), "%d %lf %lf %lf %lf %lf %lf %lf", &matches, &sf2s, &v[0],
+                      &v[1], &v[2], &v[3], &v[4], &v[5]) != 8)
+        return SIM3OPT_ERR_IO;
+      if (v[0] == 0 || v[1] == 0 || v[2] == 0) return SIM3OPT_ERR_IO;  // reference asserts (:190)
+      double R[9];
+      euler_rpy_to_R(v[0], v[1], v[2], R);
+      Loop L;
+      L.f1 = (int)f1; L.f2 = (int)f2;
+      sim3::quat_from_R(R, L.C.q);
+      L.C.t[0] = v[3]; L.C.t[1] = v[4]; L.C.t[2] = v[5];
+      L.C.s = sf2s;
+      loops.push_back(L);
+    }
+  }
+  if (loops.empty()) return SIM3OPT_ERR_IO;
+  if (use_one) loops.resize(1);  // bUseOneContraint (:568-573)
+  std::map<int, int> frame2kf;   // :575-590
+  for (size_t k = 0; k < cc.size(); ++k) frame2kf[cc[k]] = (int)k;
+  double a[8];
+  for (size_t k = 0; k < cc.size(); ++k) {  // vertices: id = keyframe id, vertex 0 fixed (:597-622)
+    to_array(Siw[k], a);
+    const int rc = sim3opt_add_vertex(g, (int32_t)k, a, k == 0);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  for (const Loop& L : loops) {  // loop edges: setVertex(0, id1), setVertex(1, id2) (:624-640)
+    auto i1 = frame2kf.find(L.f1), i2 = frame2kf.find(L.f2);
+    if (i1 == frame2kf.end() || i2 == frame2kf.end()) return SIM3OPT_ERR_IO;
+    to_array(L.C, a);
+    const int rc = sim3opt_add_edge(g, i1->second, i2->second, a, nullptr, SIM3OPT_KERNEL_NONE, 0.0);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  for (size_t i = 1; i < cc.size(); ++i) {  // odometry: Sji = Sjw * Swi, v0 = i, v1 = i-1 (:649-670)
+    const Sim3 Sji = sim3::mul(Siw[i - 1], sim3::inverse(Siw[i]));
+    to_array(Sji, a);
+    const int rc = sim3opt_add_edge(g, (int32_t)i, (int32_t)(i - 1), a, nullptr, SIM3OPT_KERNEL_NONE, 0.0);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  return SIM3OPT_OK;
+}
+
+extern "C" int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids) {
+  if (!g || !path) return SIM3OPT_ERR_ARG;
+  const int32_t nv = sim3opt_num_vertices(g);
+  std::vector<double> st(8 * (size_t)(nv > 0 ? nv : 1));
+  const int rc = sim3opt_get_vertices(g, st.data());
+  if (rc != SIM3OPT_OK) return rc;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return SIM3OPT_ERR_IO;
+  std::fprintf(f, "%% sim3 optimization result: kf id, sw2i, scaled tiinw, ri2w(qxyzw):\n");
+  for (int32_t k = 0; k < nv; ++k) {
+    Sim3 S;
+    const double* a = &st[8 * (size_t)k];
+    S.q[0] = a[0]; S.q[1] = a[1]; S.q[2] = a[2]; S.q[3] = a[3];
+    S.t[0] = a[4]; S.t[1] = a[5]; S.t[2] = a[6]; S.s = a[7];
+    const Sim3 Swi = sim3::inverse(S);  // vCorrectedSwc (:691)
+    std::fprintf(f, "%d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n",
+                 image_ids ? image_ids[k] : k, S.s, Swi.t[0], Swi.t[1], Swi.t[2], Swi.q[0],
+                 Swi.q[1], Swi.q[2], Swi.q[3]);
+  }
+  std::fclose(f);
+  return SIM3OPT_OK;
+}

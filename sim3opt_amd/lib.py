@@ -1,0 +1,357 @@
+"""ctypes binding of the C-ABI (include/sim3opt.h) -- used by tests/ and bench.py.
+
+This is plumbing, not the product: every call lands in libsim3opt.so (HIP, gfx950).
+There is no Python/CPU fallback; a missing library raises at import of the symbol table
+and a missing GPU makes `Graph.initialize()` raise Sim3OptError(SIM3OPT_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsim3opt.so")
+
+OK, ERR_ARG, ERR_STATE, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+KERNEL_NONE, KERNEL_HUBER = 0, 1
+JAC_NUMERIC, JAC_ANALYTIC = 0, 1
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("tau", C.c_double),
+        ("user_lambda_init", C.c_double),
+        ("good_step_lower", C.c_double),
+        ("good_step_upper", C.c_double),
+        ("max_trials", C.c_int32),
+        ("jacobian_mode", C.c_int32),
+        ("fd_delta", C.c_double),
+        ("exp_eps", C.c_double),
+        ("small_rot_half", C.c_int32),
+        ("fix_small_angle_b", C.c_int32),
+        ("pcg_max_iters", C.c_int32),
+        ("pcg_rel_tol", C.c_double),
+        ("pcg_check_every", C.c_int32),
+        ("device", C.c_int32),
+        ("verbose", C.c_int32),
+        ("time_kernels", C.c_int32),
+    ]
+
+
+class IterStats(C.Structure):
+    _fields_ = [
+        ("chi2_before", C.c_double),
+        ("chi2_after", C.c_double),
+        ("lambda_", C.c_double),
+        ("rho", C.c_double),
+        ("trials", C.c_int32),
+        ("pcg_iters", C.c_int32),
+        ("pcg_rel_res", C.c_double),
+        ("ms_linearize", C.c_double),
+        ("ms_solve", C.c_double),
+        ("ms_update", C.c_double),
+    ]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [
+        ("ms_spmv", C.c_double), ("n_spmv", C.c_int64),
+        ("ms_pcg_vec", C.c_double), ("n_pcg_vec", C.c_int64),
+        ("ms_linearize", C.c_double), ("n_linearize", C.c_int64),
+        ("ms_chi2", C.c_double), ("n_chi2", C.c_int64),
+        ("ms_update", C.c_double), ("n_update", C.c_int64),
+    ]
+
+
+# every symbol include/sim3opt.h declares, with its signature
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+SYMBOLS = {
+    "sim3opt_version": (C.c_int, []),
+    "sim3opt_options_default": (None, [C.POINTER(Options)]),
+    "sim3opt_create": (_vp, []),
+    "sim3opt_destroy": (None, [_vp]),
+    "sim3opt_set_options": (C.c_int, [_vp, C.POINTER(Options)]),
+    "sim3opt_get_options": (C.c_int, [_vp, C.POINTER(Options)]),
+    "sim3opt_last_error": (C.c_char_p, [_vp]),
+    "sim3opt_add_vertex": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32]),
+    "sim3opt_add_vertices": (C.c_int, [_vp, C.c_int32, _ip, _dp, _up]),
+    "sim3opt_add_edge": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _dp, C.c_int32, C.c_double]),
+    "sim3opt_add_edges": (C.c_int, [_vp, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, C.c_double]),
+    "sim3opt_num_vertices": (C.c_int32, [_vp]),
+    "sim3opt_num_edges": (C.c_int32, [_vp]),
+    "sim3opt_get_edge": (C.c_int, [_vp, C.c_int32, _ip, _ip, _dp]),
+    "sim3opt_initialize": (C.c_int, [_vp]),
+    "sim3opt_optimize": (C.c_int, [_vp, C.c_int32]),
+    "sim3opt_get_vertex": (C.c_int, [_vp, C.c_int32, _dp]),
+    "sim3opt_set_vertex": (C.c_int, [_vp, C.c_int32, _dp]),
+    "sim3opt_get_vertices": (C.c_int, [_vp, _dp]),
+    "sim3opt_set_vertices": (C.c_int, [_vp, _dp]),
+    "sim3opt_chi2": (C.c_int, [_vp, _dp]),
+    "sim3opt_num_iterations": (C.c_int32, [_vp]),
+    "sim3opt_get_stats": (C.c_int, [_vp, C.c_int32, C.POINTER(IterStats)]),
+    "sim3opt_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes)]),
+    "sim3opt_reset_kernel_times": (C.c_int, [_vp]),
+    "sim3opt_edge_errors": (C.c_int, [_vp, _dp]),
+    "sim3opt_linearize": (C.c_int, [_vp]),
+    "sim3opt_system_dims": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64)]),
+    "sim3opt_get_system": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
+    "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
+    "sim3opt_comm_unique_id": (C.c_int, [_up]),
+    "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
+    "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
+    "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
+    "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libsim3opt.so and binds every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not built: run `python -m sim3opt_amd.build` (hipcc, gfx950)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Sim3OptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sim3opt error {code}: {msg}")
+        self.code = code
+
+
+def default_options(**kw):
+    o = Options()
+    load().sim3opt_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Graph:
+    """Thin object wrapper over sim3opt_graph* (one per optimiser, like g2o::SparseOptimizer)."""
+
+    def __init__(self, **options):
+        self._L = load()
+        self._g = self._L.sim3opt_create()
+        if not self._g:
+            raise MemoryError("sim3opt_create")
+        if options:
+            self.set_options(**options)
+
+    def close(self):
+        if self._g:
+            self._L.sim3opt_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise Sim3OptError(rc, self._L.sim3opt_last_error(self._g).decode())
+        return rc
+
+    # ---- configuration ----
+    def set_options(self, **kw):
+        o = Options()
+        self._chk(self._L.sim3opt_get_options(self._g, C.byref(o)))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        self._chk(self._L.sim3opt_set_options(self._g, C.byref(o)))
+
+    def options(self):
+        o = Options()
+        self._chk(self._L.sim3opt_get_options(self._g, C.byref(o)))
+        return o
+
+    # ---- graph construction ----
+    def add_vertex(self, vid, state, fixed=False):
+        s = _f64(state)
+        self._chk(self._L.sim3opt_add_vertex(self._g, int(vid), _p(s, _dp), int(bool(fixed))))
+
+    def add_vertices(self, states, fixed=None, ids=None):
+        s = _f64(states).reshape(-1, 8)
+        f = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+        i = None if ids is None else _i32(ids)
+        self._chk(self._L.sim3opt_add_vertices(self._g, s.shape[0], _p(i, _ip), _p(s, _dp),
+                                               _p(f, _up)))
+
+    def add_edge(self, v0, v1, meas, info=None, kernel=KERNEL_NONE, kernel_delta=0.0):
+        m = _f64(meas)
+        inf = None if info is None else np.asfortranarray(info, dtype=np.float64).ravel(order="F")
+        self._chk(self._L.sim3opt_add_edge(self._g, int(v0), int(v1), _p(m, _dp), _p(inf, _dp),
+                                           int(kernel), float(kernel_delta)))
+
+    def add_edges(self, v0, v1, meas, info=None, kernel=KERNEL_NONE, kernel_delta=0.0):
+        a, b = _i32(v0), _i32(v1)
+        m = _f64(meas).reshape(-1, 8)
+        inf = None
+        if info is not None:  # (m, 7, 7) [k, r, c] -> column-major blocks
+            inf = _f64(np.asarray(info).reshape(-1, 7, 7).transpose(0, 2, 1)).reshape(-1, 49)
+        self._chk(self._L.sim3opt_add_edges(self._g, a.shape[0], _p(a, _ip), _p(b, _ip),
+                                            _p(m, _dp), _p(inf, _dp), int(kernel),
+                                            float(kernel_delta)))
+
+    @property
+    def num_vertices(self):
+        return self._L.sim3opt_num_vertices(self._g)
+
+    @property
+    def num_edges(self):
+        return self._L.sim3opt_num_edges(self._g)
+
+    def get_edge(self, k):
+        a, b = C.c_int32(), C.c_int32()
+        m = np.empty(8)
+        self._chk(self._L.sim3opt_get_edge(self._g, int(k), C.byref(a), C.byref(b), _p(m, _dp)))
+        return a.value, b.value, m
+
+    # ---- optimisation ----
+    def initialize(self):
+        self._chk(self._L.sim3opt_initialize(self._g))
+
+    def optimize(self, max_iters):
+        """Returns iterations executed (g2o convention: 0 failure, -1 nothing to do)."""
+        it = self._L.sim3opt_optimize(self._g, int(max_iters))
+        if it == 0 and max_iters > 0:
+            raise Sim3OptError(0, self._L.sim3opt_last_error(self._g).decode())
+        return it
+
+    def chi2(self):
+        v = C.c_double()
+        self._chk(self._L.sim3opt_chi2(self._g, C.byref(v)))
+        return v.value
+
+    def get_vertex(self, vid):
+        s = np.empty(8)
+        self._chk(self._L.sim3opt_get_vertex(self._g, int(vid), _p(s, _dp)))
+        return s
+
+    def set_vertex(self, vid, state):
+        s = _f64(state)
+        self._chk(self._L.sim3opt_set_vertex(self._g, int(vid), _p(s, _dp)))
+
+    def get_vertices(self):
+        s = np.empty((self.num_vertices, 8))
+        self._chk(self._L.sim3opt_get_vertices(self._g, _p(s, _dp)))
+        return s
+
+    def set_vertices(self, states):
+        s = _f64(states).reshape(-1, 8)
+        assert s.shape[0] == self.num_vertices
+        self._chk(self._L.sim3opt_set_vertices(self._g, _p(s, _dp)))
+
+    def stats(self):
+        out = []
+        for i in range(self._L.sim3opt_num_iterations(self._g)):
+            st = IterStats()
+            self._chk(self._L.sim3opt_get_stats(self._g, i, C.byref(st)))
+            out.append(st)
+        return out
+
+    def kernel_times(self, reset=False):
+        kt = KernelTimes()
+        self._chk(self._L.sim3opt_get_kernel_times(self._g, C.byref(kt)))
+        if reset:
+            self._chk(self._L.sim3opt_reset_kernel_times(self._g))
+        return kt
+
+    # ---- kernel-level access ----
+    def edge_errors(self):
+        e = np.empty((self.num_edges, 7))
+        self._chk(self._L.sim3opt_edge_errors(self._g, _p(e, _dp)))
+        return e
+
+    def linearize(self):
+        self._chk(self._L.sim3opt_linearize(self._g))
+
+    def system_dims(self):
+        nb, nnzb = C.c_int32(), C.c_int64()
+        self._chk(self._L.sim3opt_system_dims(self._g, C.byref(nb), C.byref(nnzb)))
+        return nb.value, nnzb.value
+
+    def get_system(self):
+        """(rowptr, colidx, blocks[nnzb, 7, 7] indexed [k, r, c], b)."""
+        nb, nnzb = self.system_dims()
+        rowptr = np.empty(nb + 1, dtype=np.int32)
+        colidx = np.empty(nnzb, dtype=np.int32)
+        vals = np.empty((nnzb, 49))
+        b = np.empty(7 * nb)
+        self._chk(self._L.sim3opt_get_system(self._g, _p(rowptr, _ip), _p(colidx, _ip),
+                                             _p(vals, _dp), _p(b, _dp)))
+        return rowptr, colidx, vals.reshape(-1, 7, 7).transpose(0, 2, 1).copy(), b
+
+    def dense_system(self):
+        """Dense (H, b) assembled from the block-CSR copy (small graphs, tests only)."""
+        rowptr, colidx, blocks, b = self.get_system()
+        nb = rowptr.shape[0] - 1
+        H = np.zeros((7 * nb, 7 * nb))
+        for i in range(nb):
+            for k in range(rowptr[i], rowptr[i + 1]):
+                j = colidx[k]
+                H[7 * i:7 * i + 7, 7 * j:7 * j + 7] += blocks[k]
+        return H, b
+
+    def solve(self, lam):
+        nb, _ = self.system_dims()
+        x = np.empty(7 * nb)
+        it = C.c_int32()
+        rr = C.c_double()
+        self._chk(self._L.sim3opt_solve(self._g, float(lam), _p(x, _dp), C.byref(it),
+                                        C.byref(rr)))
+        return x, it.value, rr.value
+
+    def bench_spmv(self, reps=20):
+        ms = C.c_double()
+        self._chk(self._L.sim3opt_bench_spmv(self._g, int(reps), C.byref(ms)))
+        return ms.value
+
+    # ---- reference-format I/O ----
+    def load_kitti_direct(self, directory, use_one_constraint=True):
+        self._chk(self._L.sim3opt_load_kitti_direct(self._g, os.fsencode(directory),
+                                                    int(bool(use_one_constraint))))
+
+    def write_poses(self, path, image_ids=None):
+        ids = None if image_ids is None else _i32(image_ids)
+        self._chk(self._L.sim3opt_write_poses(self._g, os.fsencode(path), _p(ids, _ip)))
+
+
+def partition_rows(rowptr, world):
+    rp = _i32(rowptr)
+    out = np.empty(world + 1, dtype=np.int32)
+    rc = load().sim3opt_partition_rows(rp.shape[0] - 1, _p(rp, _ip), int(world), _p(out, _ip))
+    if rc != OK:
+        raise Sim3OptError(rc, "partition_rows")
+    return out

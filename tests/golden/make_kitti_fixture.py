@@ -1,0 +1,28 @@
+"""Vendors the KITTI-00 pose-graph INPUT DATA the hot path consumes.
+
+Run in the build container only (needs /root/reference/data).  Copies data files, no source:
+  cc.txt               -- keyframe image ids            (read by kitti_surf.cpp:232-254)
+  loopConstraints.txt  -- 118 loop constraints          (read by kitti_surf.cpp:145-205)
+  framePoses_kf.txt    -- the 2 header lines + only the 771 keyframe rows of framePoses.txt
+                          (kitti_surf.cpp:255-292 keeps exactly these rows)
+"""
+import os
+import shutil
+
+SRC = "/root/reference/data/map000000"
+DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kitti00")
+
+os.makedirs(DST, exist_ok=True)
+shutil.copyfile(os.path.join(SRC, "cc.txt"), os.path.join(DST, "cc.txt"))
+shutil.copyfile(os.path.join(SRC, "loopConstraints.txt"), os.path.join(DST, "loopConstraints.txt"))
+ids = {int(x) for x in open(os.path.join(SRC, "cc.txt")).read().split()}
+with open(os.path.join(SRC, "framePoses.txt")) as f, \
+        open(os.path.join(DST, "framePoses_kf.txt"), "w") as g:
+    lines = f.read().splitlines()
+    g.write(lines[0] + "\n" + lines[1] + "\n")
+    n = 0
+    for ln in lines[2:]:
+        if ln.strip() and int(ln.split(",")[0]) in ids:
+            g.write(ln + "\n")
+            n += 1
+print("keyframes", len(ids), "rows kept", n)

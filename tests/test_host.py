@@ -1,0 +1,148 @@
+"""CPU tests of the host side of libsim3opt: the C-ABI surface, the graph container's error
+behaviour (g2o's bool/int conventions turned into status codes), the reference-format loader and
+the row partition.  No compute call is made here -- without a GPU the library must fail loudly.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sim3opt_amd import lib as L, sim3np as S3
+import kitti_graph as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+I8 = [0, 0, 0, 1, 0, 0, 0, 1.0]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sim3opt.h")).read()
+    declared = set(re.findall(r"\b(sim3opt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sim3opt_graph", "sim3opt_options", "sim3opt_iter_stats", "sim3opt_kernel_times"}
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.load()  # binds every symbol, raises AttributeError on a missing export
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sim3opt_version() >= 100
+
+
+def test_options_struct_matches_header_defaults():
+    o = L.default_options()
+    assert o.tau == 1e-5 and o.max_trials == 10 and o.fd_delta == 1e-9 and o.exp_eps == 1e-5
+    assert abs(o.good_step_lower - 1 / 3) < 1e-16 and abs(o.good_step_upper - 2 / 3) < 1e-16
+    assert o.jacobian_mode == L.JAC_NUMERIC and o.fix_small_angle_b == 0 and o.device == -1
+    # field-by-field agreement between the ctypes mirror and the C header
+    hdr = open(os.path.join(ROOT, "include", "sim3opt.h")).read()
+    body = hdr[hdr.index("typedef struct sim3opt_options {"):hdr.index("} sim3opt_options;")]
+    fields = re.findall(r"^\s*(?:double|int32_t)\s+([a-z_0-9]+);", body, flags=re.M)
+    assert fields == [f[0] for f in L.Options._fields_]
+    G = L.Graph(pcg_rel_tol=1e-6, verbose=1)
+    assert G.options().pcg_rel_tol == 1e-6 and G.options().verbose == 1
+    with pytest.raises(L.Sim3OptError):
+        G.set_options(fd_delta=0.0)
+
+
+def test_graph_container_error_codes():
+    G = L.Graph()
+    G.add_vertex(10, I8, fixed=True)
+    G.add_vertex(-7, I8)
+    with pytest.raises(L.Sim3OptError) as ei:  # duplicate id: g2o's addVertex returns false
+        G.add_vertex(10, I8)
+    assert ei.value.code == L.ERR_ARG
+    with pytest.raises(L.Sim3OptError):  # unknown endpoint
+        G.add_edge(10, 99, I8)
+    with pytest.raises(L.Sim3OptError):  # identical endpoints
+        G.add_edge(10, 10, I8)
+    with pytest.raises(L.Sim3OptError):  # non-positive scale
+        G.add_edge(10, -7, [0, 0, 0, 1, 0, 0, 0, 0.0])
+    with pytest.raises(L.Sim3OptError):  # NaN state
+        G.add_vertex(3, [np.nan, 0, 0, 1, 0, 0, 0, 1])
+    with pytest.raises(L.Sim3OptError):  # Huber needs delta > 0
+        G.add_edge(10, -7, I8, kernel=L.KERNEL_HUBER, kernel_delta=0.0)
+    G.add_edge(10, -7, I8)
+    assert (G.num_vertices, G.num_edges) == (2, 1)
+    a, b, m = G.get_edge(0)
+    assert (a, b) == (10, -7) and np.array_equal(m, I8)
+    # estimates can be read and warm-started before initialize (vertex objects in g2o)
+    s = np.array([0, 0, 0, 1, 1, 2, 3, 1.5])
+    G.set_vertex(-7, s)
+    assert np.array_equal(G.get_vertex(-7), s)
+    with pytest.raises(L.Sim3OptError):
+        G.get_vertex(12345)
+    # compute entry points refuse to run before initialize
+    for fn in (G.chi2, G.linearize, G.edge_errors):
+        with pytest.raises(L.Sim3OptError) as ei:
+            fn()
+        assert ei.value.code == L.ERR_STATE
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a HIP device initialize() must fail loudly, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    G = L.Graph()
+    G.add_vertices(np.tile(I8, (3, 1)), [1, 0, 0])
+    G.add_edges([1, 2], [0, 1], np.tile(I8, (2, 1)))
+    with pytest.raises(L.Sim3OptError) as ei:
+        G.initialize()
+    assert ei.value.code == L.ERR_NO_DEVICE
+    with pytest.raises(L.Sim3OptError):
+        G.optimize(5)
+
+
+def test_nothing_to_optimise_conventions():
+    G = L.Graph()
+    assert G._L.sim3opt_optimize(G._g, 10) == -1  # empty graph: g2o returns -1
+    G.add_vertices(np.tile(I8, (2, 1)), [1, 1])
+    G.add_edges([1], [0], [I8])
+    with pytest.raises(L.Sim3OptError) as ei:  # all vertices fixed
+        G.initialize()
+    assert ei.value.code in (L.ERR_STATE, L.ERR_NO_DEVICE)
+
+
+@pytest.mark.parametrize("one", [True, False])
+def test_kitti_loader_matches_python_builder(one):
+    """C++ loader (kitti_io.cpp, mirrors kitti_surf.cpp:145-292, 575-670) vs the numpy builder."""
+    ref = K.build_direct_graph(one)
+    G = L.Graph()
+    G.load_kitti_direct(K.FIXTURE, one)
+    assert G.num_vertices == 771 and G.num_edges == (771 if one else 888)
+    st = G.get_vertices()
+    assert np.abs(st - ref["states"]).max() < 1e-12
+    for k in list(range(0, G.num_edges, 37)) + [G.num_edges - 1]:
+        a, b, m = G.get_edge(k)
+        assert (a, b) == (ref["v0"][k], ref["v1"][k])
+        assert np.abs(m - ref["meas"][k]).max() < 1e-12
+    with pytest.raises(L.Sim3OptError) as ei:
+        L.Graph().load_kitti_direct("/nonexistent/dir", True)
+    assert ei.value.code == L.ERR_IO
+
+
+def test_write_poses_format(tmp_path):
+    G = L.Graph()
+    G.load_kitti_direct(K.FIXTURE, True)
+    path = str(tmp_path / "direct_pure.txt")
+    G.write_poses(path, K.load_cc())
+    lines = open(path).read().splitlines()
+    assert lines[0].startswith("%") and len(lines) == 772
+    row = [float(x) for x in lines[6].split()]
+    st = G.get_vertices()[5]
+    Swi = S3.inv(st)
+    assert int(row[0]) == K.load_cc()[5] and row[1] == st[7]
+    assert np.abs(np.array(row[2:5]) - Swi[4:7]).max() < 1e-15
+    assert np.abs(np.array(row[5:9]) - Swi[:4]).max() < 1e-15
+
+
+def test_partition_rows_balances_blocks():
+    rng = np.random.default_rng(0)
+    deg = rng.integers(1, 30, size=1000)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    for world in (1, 2, 3, 8):
+        beg = L.partition_rows(rowptr, world)
+        assert beg[0] == 0 and beg[-1] == 1000 and np.all(np.diff(beg) >= 0)
+        loads = [rowptr[beg[r + 1]] - rowptr[beg[r]] for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * deg.max()
+    beg = L.partition_rows(np.array([0, 5], dtype=np.int32), 4)  # fewer rows than ranks
+    assert beg[0] == 0 and beg[-1] == 1 and np.all(np.diff(beg) >= 0)
