@@ -80,20 +80,24 @@ int add_edge_impl(sim3opt_graph* g, int32_t id0, int32_t id1, const double* meas
   HostGraph& h = g->host;
   const size_t m = h.ev0.size();
   const bool nonident = info && !is_identity77(info);
-  if (nonident && h.info.empty()) {  // first non-identity information: materialise I7 for earlier edges
+  if (nonident && !h.has_info) {  // first non-identity information: materialise I7 for earlier edges
+    h.has_info = true;
     h.info.assign(49 * m, 0.0);
     for (size_t k = 0; k < m; ++k)
       for (int d = 0; d < 7; ++d) h.info[49 * k + 8 * d] = 1.0;
   }
-  if (!h.info.empty()) {
+  if (h.has_info) {
     const size_t off = h.info.size();
     h.info.resize(off + 49, 0.0);
     if (info) std::memcpy(&h.info[off], info, sizeof(double) * 49);
     else for (int d = 0; d < 7; ++d) h.info[off + 8 * d] = 1.0;
   }
   const bool has_k = kernel == SIM3OPT_KERNEL_HUBER;
-  if (has_k && h.kdelta.empty()) h.kdelta.assign(m, 0.0);
-  if (!h.kdelta.empty()) h.kdelta.push_back(has_k ? kdelta : 0.0);
+  if (has_k && !h.has_kernel) {
+    h.has_kernel = true;
+    h.kdelta.assign(m, 0.0);
+  }
+  if (h.has_kernel) h.kdelta.push_back(has_k ? kdelta : 0.0);
   h.ev0.push_back(a->second);
   h.ev1.push_back(b->second);
   h.meas.push_back(to_sim3(meas));

@@ -674,8 +674,8 @@ class Engine {
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
     n_active = (int32_t)s.active.size();
-    has_info = !g.info.empty();
-    has_kernel = !g.kdelta.empty();
+    has_info = g.has_info;
+    has_kernel = g.has_kernel;
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ev_a));
     HIPCHK(hipEventCreate(&ev_b));

@@ -25,8 +25,10 @@ struct HostGraph {
   // edges, insertion order; endpoints as vertex indices
   std::vector<int32_t> ev0, ev1;
   std::vector<sim3::Sim3> meas;
-  std::vector<double> info;    // empty while every edge has identity information, else m x 49
-  std::vector<double> kdelta;  // empty while no edge has a robust kernel, else m (0 = none, >0 = Huber)
+  bool has_info = false;       // some edge carries a non-identity information matrix
+  bool has_kernel = false;     // some edge carries a robust kernel
+  std::vector<double> info;    // m x 49 once has_info, else empty
+  std::vector<double> kdelta;  // m once has_kernel (0 = none, >0 = Huber delta), else empty
 
   int32_t nv() const { return (int32_t)vid.size(); }
   int32_t ne() const { return (int32_t)ev0.size(); }

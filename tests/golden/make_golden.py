@@ -69,17 +69,24 @@ for name, one in (("one_loop", True), ("all_loops", False)):
 out["kitti"] = kit
 
 # ---- small seeded synthetic graphs, well-posed mode (fix_small_angle_b = 1) ----
+# two finite-difference steps: g2o's 1e-9 (Jacobian noise ~1e-7, LM stalls at that floor) and
+# 1e-6 (noise ~1e-10: both implementations reach the same optimum to ~1e-7)
 syn = {}
 synth.DRIFT_TARGET = 0.05
 for name, g in (("manhattan_120", synth.manhattan(120, 1000, dims=(6, 6, 3), per_cell=4)),
                 ("chain_150", synth.chain_loop(150, 300))):
-    G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
-    o = O.default_options(fix_small_angle_b=1)
-    chi0 = G.chi2(o)
-    it, tr = G.optimize(15, o)
-    syn[name] = dict(chi2_0=chi0, iters=it, chi2_final=tr[-1].chi2_after,
-                     positions=synth.positions(G.states).tolist(),
-                     scales=G.states[:, 7].tolist())
+    rec = {}
+    for tag, fd in (("fd1e9", 1e-9), ("fd1e6", 1e-6)):
+        G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
+        o = O.default_options(fix_small_angle_b=1, fd_delta=fd)
+        chi0 = G.chi2(o)
+        it, tr = G.optimize(15, o)
+        rec[tag] = dict(chi2_0=chi0, iters=it, chi2_final=tr[-1].chi2_after,
+                        positions=synth.positions(G.states).tolist(),
+                        scales=G.states[:, 7].tolist())
+    d = np.array(rec["fd1e9"]["positions"]) - np.array(rec["fd1e6"]["positions"])
+    rec["rmse_between_fd_steps"] = float(np.sqrt((d ** 2).sum(1).mean()))
+    syn[name] = rec
 out["synthetic_fixb"] = syn
 
 with open(os.path.join(HERE, "oracle_golden.json"), "w") as f:

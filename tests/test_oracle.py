@@ -320,7 +320,7 @@ def test_lm_policy_and_return_codes():
 
 @pytest.mark.parametrize("name", ["manhattan_120", "chain_150"])
 def test_synthetic_golden_fixb(name):
-    gold = GOLD["synthetic_fixb"][name]
+    gold = GOLD["synthetic_fixb"][name]["fd1e9"]
     synth.DRIFT_TARGET = 0.05
     g = (synth.manhattan(120, 1000, dims=(6, 6, 3), per_cell=4) if name == "manhattan_120"
          else synth.chain_loop(150, 300))
