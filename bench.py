@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--edges", type=int, default=1000000)
-    ap.add_argument("--fix-small-angle-b", type=int, default=0,
-                    help="0 = reference arithmetic as written (default), 1 = exact small-angle limit")
+    ap.add_argument("--fix-small-angle-b", type=int, default=1,
+                    help="1 (default) = exact small-angle B coefficient: LM converges on this graph; "
+                         "0 = reference arithmetic as written (sim3_rv.h:166): LM stalls at "
+                         "lambda ~1e8, reported separately as reference_arithmetic")
     ap.add_argument("--pcg-rel-tol", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vertices", type=int, default=1000)
@@ -196,6 +198,32 @@ def main():
             "ms_update_mean": float(np.mean([s.ms_update for s in stats])),
             "roofline": roof,
         }
+        if world == 1 and args.fix_small_angle_b == 1:
+            # same K steps in the reference's as-written arithmetic (not part of `value`)
+            R = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, fix_small_angle_b=0)
+            R.add_vertices(g["states"], g["fixed"])
+            R.add_edges(g["v0"], g["v1"], g["meas"])
+            R.initialize()
+            r0 = R.chi2()
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            rdone, rstats = 0, []
+            while rdone < K:
+                it = R._L.sim3opt_optimize(R._g, K - rdone)
+                if it <= 0:
+                    break
+                rdone += it
+                rstats += R.stats()
+            torch.cuda.synchronize()
+            rdt = time.perf_counter() - tr0
+            out["reference_arithmetic"] = {
+                "fix_small_angle_b": 0, "steps": rdone, "value": rdone / rdt, "unit": "LM iter/s",
+                "chi2_initial": r0, "chi2_final": R.chi2(),
+                "pcg_iters": [int(s.pcg_iters) for s in rstats],
+                "lambda_last": rstats[-1].lambda_ if rstats else None,
+                "note": "B coefficient as written in sim3_rv.h:166/:290: lambda_0 = 1e-5 * max|H_dd| "
+                        "is ~1e8 and LM barely moves (DESIGN.md)"}
+            R.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
             out["speedup_vs_cpu_edges_iters"] = out["edges_iters_per_s"] / out["cpu_baseline"]["value"]

@@ -57,7 +57,7 @@ typedef struct sim3opt_options {
   int32_t small_rot_half;   /* 0     R = I+W+W^2 (sim3_rv.h:151); 1: I+W+W^2/2           */
   int32_t fix_small_angle_b;/* 0     B coefficient as written in sim3_rv.h:166/:290 (reference
                                         behaviour); 1: exact small-theta limit               */
-  int32_t pcg_max_iters;    /* 0 = automatic (7 * free vertices, capped)                 */
+  int32_t pcg_max_iters;    /* 0 = automatic: min(max(7*free vertices, 100), 1000)       */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */

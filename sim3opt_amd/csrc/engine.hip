@@ -827,7 +827,7 @@ class Engine {
     const int gv = grid_for((nb + 8) / 9, 4);  // 36 block rows per workgroup pass
     const int gs = grid_for(nb, 4);
     const int ge = grid_for(n, WG);
-    int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 20000);
+    int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
     const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
     HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, nb, d_rowptr, d_vals, lambda,

@@ -13,9 +13,10 @@ Formulae follow the in-tree authority sim3_rv.h:125-190 (exp), :242-320 (ln),
 import numpy as np
 
 EPS = 1e-5
-# 0: small-theta B coefficient as written in sim3_rv.h:166/:290 (reference behaviour);
-# 1: exact limit.  Data generation (synth.py) is unaffected: it never hits that branch with
-# a measurable difference (exp only takes it for theta < 1e-5).
+# Default of the `fix_b` argument of exp/log below.  0: small-theta B coefficient as written in
+# sim3_rv.h:166/:290 (reference behaviour, B ~ 1/sigma^3); 1: exact limit.  Data generation
+# (synth.py) always passes fix_b=True: with the as-written B a noise vector with theta < 1e-5
+# and |sigma| > 1e-5 would get its translation multiplied by ~1e3 and corrupt the graph.
 FIX_SMALL_ANGLE_B = 0
 
 
@@ -129,7 +130,7 @@ def _skew(w):
     return W
 
 
-def _abc(sigma, s, theta, small_theta):
+def _abc(sigma, s, theta, small_theta, fix_b):
     small_sigma = np.abs(sigma) < EPS
     th = np.where(small_theta, 1.0, theta)
     sg = np.where(small_sigma, 1.0, sigma)
@@ -137,7 +138,7 @@ def _abc(sigma, s, theta, small_theta):
     B0 = np.where(small_theta, 1.0 / 6.0, (th - np.sin(th)) / th ** 3)
     C1 = (s - 1) / sg
     A1s = ((sg - 1) * s + 1) / sg ** 2
-    B1s = ((0.5 * sg ** 2 - sg + 1) * s - (1.0 if FIX_SMALL_ANGLE_B else 0.0)) / sg ** 3
+    B1s = ((0.5 * sg ** 2 - sg + 1) * s - (1.0 if fix_b else 0.0)) / sg ** 3
     a, b, c = s * np.sin(th), s * np.cos(th), th ** 2 + sg ** 2
     A1 = (a * sg + (1 - b) * th) / (th * c)
     B1 = (C1 - ((b - 1) * sg + a * th) / c) / th ** 2
@@ -147,7 +148,8 @@ def _abc(sigma, s, theta, small_theta):
     return A, B, Cc
 
 
-def exp(xi):
+def exp(xi, fix_b=None):
+    fix_b = FIX_SMALL_ANGLE_B if fix_b is None else fix_b
     xi = np.asarray(xi, dtype=np.float64)
     om, up, sigma = xi[..., :3], xi[..., 3:6], xi[..., 6]
     theta = np.linalg.norm(om, axis=-1)
@@ -155,7 +157,7 @@ def exp(xi):
     Om = _skew(om)
     Om2 = Om @ Om
     s = np.exp(sigma)
-    A, B, Cc = _abc(sigma, s, theta, small)
+    A, B, Cc = _abc(sigma, s, theta, small, fix_b)
     th = np.where(small, 1.0, theta)
     k1 = np.where(small, 1.0, np.sin(th) / th)
     k2 = np.where(small, 1.0, (1 - np.cos(th)) / th ** 2)
@@ -166,7 +168,8 @@ def exp(xi):
     return make(R_to_quat(R), t, s)
 
 
-def log(S):
+def log(S, fix_b=None):
+    fix_b = FIX_SMALL_ANGLE_B if fix_b is None else fix_b
     S = np.asarray(S, dtype=np.float64)
     s = S[..., 7]
     sigma = np.log(s)
@@ -179,16 +182,16 @@ def log(S):
     theta = np.where(small, 0.0, np.arccos(dc))
     k = np.where(small, 0.5, theta / (2 * np.sqrt(np.maximum(1 - dc * dc, 1e-300))))
     om = k[..., None] * dR
-    A, B, Cc = _abc(sigma, s, theta, small)
+    A, B, Cc = _abc(sigma, s, theta, small, fix_b)
     Om = _skew(om)
     W = A[..., None, None] * Om + B[..., None, None] * (Om @ Om) + Cc[..., None, None] * np.eye(3)
     up = np.linalg.solve(W, S[..., 4:7, None])[..., 0]
     return np.concatenate([om, up, sigma[..., None]], axis=-1)
 
 
-def edge_error(C, S0, S1):
+def edge_error(C, S0, S1, fix_b=None):
     """EdgeSim3::computeError: log(C * S0 * S1^-1)."""
-    return log(mul(mul(C, S0), inv(S1)))
+    return log(mul(mul(C, S0), inv(S1)), fix_b)
 
 
 def identity(n=None):

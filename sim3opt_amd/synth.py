@@ -30,7 +30,8 @@ def _noise(rng, n, sig):
 
 
 def _measure(Sgt, v0, v1, xi):
-    return S3.mul(S3.exp(xi), S3.mul(Sgt[v1], S3.inv(Sgt[v0])))
+    # exact exp (fix_b): the noise must not pass through the reference's as-written B coefficient
+    return S3.mul(S3.exp(xi, fix_b=True), S3.mul(Sgt[v1], S3.inv(Sgt[v0])))
 
 
 def _dead_reckon(S0, odo_meas):
