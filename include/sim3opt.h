@@ -162,6 +162,9 @@ int sim3opt_solve(sim3opt_graph* g, double lambda, double* x /*7 nb*/, int32_t* 
                   double* rel_res);
 /* times `reps` back-to-back launches of the block-CSR SpMV kernel; returns mean ms */
 int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
+/* HBM read calibration over the same value array (bench only): mode 0 = 16 B/lane contiguous,
+ * 1 = 8 B/lane contiguous, 2 = 8 B/lane on 49 of 64 lanes per 392-B block (the SpMV's shape) */
+int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
 
 /* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
  * Call between create and initialize.  unique_id is the 128-byte ncclUniqueId produced by

@@ -357,6 +357,12 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean) {
   return engine_bench_spmv(g->engine, reps, ms_mean, g->err);
 }
 
+int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean) {
+  if (!g || !ms_mean || reps < 1 || mode < 0 || mode > 2) return fail(g, SIM3OPT_ERR_ARG, "bench_stream: bad argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_stream: call sim3opt_initialize first");
+  return engine_bench_stream(g->engine, mode, reps, ms_mean, g->err);
+}
+
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin) {
   if (n_block_rows < 0 || !rowptr || world < 1 || !row_begin) return SIM3OPT_ERR_ARG;

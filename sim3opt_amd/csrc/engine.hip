@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.hpp"
@@ -41,7 +42,8 @@ using sim3::Sim3;
   } while (0)
 
 constexpr int WG = 256;         // 4 wavefronts of 64
-constexpr int MAX_GRID = 1024;  // grid cap of the streaming kernels = number of reduction partials
+constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
+                                // (256 CUs x 8 workgroups of 4 waves = full occupancy)
 
 // Scalars that live in HBM so the PCG loop needs no host round trip per iteration.
 struct DevScalars {
@@ -400,36 +402,221 @@ __global__ __launch_bounds__(WG) void k_jacobi(int nb, const int32_t* __restrict
 // ------------------------------------------------------------------------------------------
 // q = (H + lambda I) p, partial p.q per workgroup.  One wavefront per block row, lane = one of
 // the 49 entries of the current 7x7 block; a row's blocks are one contiguous HBM stream.
+//   * CHUNK blocks are fetched back to back before any use (CHUNK x 392 B in flight per
+//     wavefront): the kernel is latency-bound otherwise;
+//   * column indices are wave-uniform (scalar loads), so the gathers of p do not wait on a
+//     vector load;
+//   * NT: the once-read block stream bypasses the cache policy so that p (7*nb doubles,
+//     re-read ~deg times) stays resident in the XCD's L2;
+//   * XCD: workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x the x-th contiguous
+//     eighth of the rows keeps each L2's share of p to the columns near that eighth.  Only speed
+//     depends on the placement, never the result.
+template <int CHUNK, bool NT>
 __global__ __launch_bounds__(WG) void k_spmv(int nb, const int32_t* __restrict__ rowptr,
                                              const int32_t* __restrict__ colidx,
                                              const double* __restrict__ vals,
                                              const double* __restrict__ p,
                                              double* __restrict__ q, double lambda,
                                              double* __restrict__ partials,
-                                             const DevScalars* __restrict__ sc) {
+                                             const DevScalars* __restrict__ sc, int xcd_map) {
   __shared__ double sh[4];
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane % 7, c = lane / 7;
-  const bool act = lane < 49;
+  const int r = lane % 7;
+  const int nchunk = (nb + 3) >> 2;  // 4 block rows per workgroup pass
+  int first = blockIdx.x, stride = gridDim.x, last = nchunk;
+  const int ablate = xcd_map >> 4;  // tuning only: 1 = skip the p gather, 2 = skip the block stream
+  if (xcd_map & 1) {
+    const int x = blockIdx.x & 7, gx = gridDim.x >> 3;
+    first = (int)((long long)nchunk * x / 8) + (blockIdx.x >> 3);
+    last = (int)((long long)nchunk * (x + 1) / 8);
+    stride = gx;
+  }
+  // lanes 49..63 mirror lanes 0..14: every lane issues a valid, coalesced load (no exec masking,
+  // no branches around the loads); their products are never read by the reduction below.
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int c49 = l49 / 7;
+  const int gu = lane / 7 < CHUNK ? lane / 7 : CHUNK - 1, gc = lane % 7;  // gather slot of this lane
   double pq = 0.0;
-  for (int row = blockIdx.x * 4 + wave; row < nb; row += gridDim.x * 4) {
-    const int k0 = rowptr[row], k1 = rowptr[row + 1];
-    double acc = 0.0;
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-      const int col = colidx[k];
-      if (act) acc += vals[(size_t)49 * k + lane] * p[(size_t)7 * col + c];
-    }
-    double y = acc;
+  // Row metadata (row pointers + the row's column indices) is fetched one row AHEAD, so a row
+  // costs one dependent memory round trip per CHUNK blocks instead of three extra ones.
+  int nk0 = 0, nnblk = 0, nmyc = 0;
+  if (first < last && first * 4 + wave < nb) {
+    const int row = first * 4 + wave;
+    nk0 = rowptr[row];
+    nnblk = rowptr[row + 1] - nk0;
+    nmyc = lane < nnblk ? colidx[nk0 + lane] : 0;
+  }
+  for (int ch = first; ch < last; ch += stride) {
+    const int row = ch * 4 + wave;
+    if (row < nb) {
+      const int k0 = nk0, nblk = nnblk;
+      const int myc0 = nmyc;
+      {
+        const int nrow = (ch + stride) * 4 + wave;
+        if (ch + stride < last && nrow < nb) {
+          nk0 = rowptr[nrow];
+          nnblk = rowptr[nrow + 1] - nk0;
+          nmyc = lane < nnblk ? colidx[nk0 + lane] : 0;
+        }
+      }
+      double acc = 0.0;
+      for (int base = 0; base < nblk; base += 64) {
+        // the row's column indices: ONE coalesced vector load (prefetched for the first 64)
+        const int myc = base == 0 ? myc0 : ((base + lane < nblk) ? colidx[k0 + base + lane] : 0);
+        const int m = nblk - base < 64 ? nblk - base : 64;
+        const double* vrow = vals + (size_t)49 * (k0 + base) + l49;
+        // CHUNK blocks per step, all loads issued before the first use; the last step re-reads
+        // the row's final block for its missing slots (cache hit) and weights them with zero
+        for (int j = 0; j < m; j += CHUNK) {
+          double v[CHUNK], xv[CHUNK];
 #pragma unroll
-    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-    if (lane < 7) {
-      const double pi = p[(size_t)7 * row + lane];
-      y += lambda * pi;
-      q[(size_t)7 * row + lane] = y;
-      pq += pi * y;
+          for (int u = 0; u < CHUNK; ++u) {
+            const int ju = j + u < m ? j + u : m - 1;
+            const double* vp = vrow + (size_t)49 * ju;
+            v[u] = ablate == 2 ? 1.0 : (NT ? __builtin_nontemporal_load(vp) : *vp);
+          }
+          // ONE gather instruction fetches the p entries of all CHUNK blocks (lane 7u+c reads
+          // p[7*col_u + c]); they reach the (r, c) lanes through the LDS crossbar (ds_bpermute),
+          // which is idle here, instead of CHUNK more trips through the address unit
+          if (ablate == 1) {
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) xv[u] = 1.0;
+          } else {
+            const int slot = j + gu < m ? j + gu : m - 1;
+            const int colu = __shfl(myc, slot);
+            const double xg = p[(size_t)7 * colu + gc];
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) xv[u] = __shfl(xg, 7 * u + c49);
+          }
+#pragma unroll
+          for (int u = 0; u < CHUNK; ++u) acc += (j + u < m ? v[u] : 0.0) * xv[u];
+        }
+      }
+      double y = acc;
+#pragma unroll
+      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
+      if (lane < 7) {
+        const double pi = p[(size_t)7 * row + lane];
+        y += lambda * pi;
+        q[(size_t)7 * row + lane] = y;
+        pq += pi * y;
+      }
+    }
+  }
+  const double s = block_sum(pq, sh);
+  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
+}
+
+// Span variant of the SpMV: each wavefront owns a CONTIGUOUS span of block rows (host table
+// `wrow`, balanced by block count), so its blocks and column indices are one contiguous stream
+// that is software-pipelined across row boundaries: the loads of chunk k+1 (CH blocks, one shared
+// gather of p) are in flight while chunk k is consumed; a row ends with a wave-uniform branch
+// (reduce 7 columns, add lambda p, store q, accumulate p.q).  Same arithmetic order per row as
+// k_spmv, so q is bit-identical; only the grouping of the p.q partials differs.
+template <int CH, bool NT>
+__global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
+                                                  const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ colidx,
+                                                  const double* __restrict__ vals,
+                                                  const double* __restrict__ p,
+                                                  double* __restrict__ q, double lambda,
+                                                  double* __restrict__ partials,
+                                                  const DevScalars* __restrict__ sc) {
+  __shared__ double sh[4];
+  if (sc && sc->done) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int r = lane % 7;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int c49 = l49 / 7;
+  const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
+  const int rA = wrow[w], rB = wrow[w + 1];
+  double pq = 0.0;
+  if (rA < rB) {
+    const int kbeg = rowptr[rA], kend = rowptr[rB];
+    // row ends of this span, 64 at a time, one per lane
+    int rbase = rA;
+    int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
+    int row = rA;
+    int k1 = __builtin_amdgcn_readlane(rpv, 0);
+    // column indices, 64 blocks at a time, one per lane; window w covers [kbeg + 64 w, +64)
+    int cbase = kbeg;
+    int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
+    int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
+    double acc = 0.0;
+    double vc[CH], vn[CH];
+    double xgc, xgn = 0.0;
+    // prologue: chunk at kbeg
+    {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int kk = kbeg + u < kend ? kbeg + u : kend - 1;
+        const double* vp = vals + (size_t)49 * kk + l49;
+        vc[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
+      }
+      const int kk = kbeg + gu < kend ? kbeg + gu : kend - 1;
+      const int colu = __shfl(cv, kk - cbase);
+      xgc = p[(size_t)7 * colu + gc];
+    }
+    for (int k = kbeg; k < kend; k += CH) {
+      const int kn = k + CH;
+      if (kn < kend) {  // issue the next chunk before consuming this one
+        if (kn - cbase >= 64) {  // next chunk starts a new 64-block window (CH divides 64)
+          cbase += 64;
+          cv = cvn;
+          cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int kk = kn + u < kend ? kn + u : kend - 1;
+          const double* vp = vals + (size_t)49 * kk + l49;
+          vn[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
+        }
+        const int kk = kn + gu < kend ? kn + gu : kend - 1;
+        const int colu = __shfl(cv, kk - cbase);
+        xgn = p[(size_t)7 * colu + gc];
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int kk = k + u;
+        if (kk < kend) {
+          if (kk == k1) {  // row `row` is complete
+            double y = acc;
+#pragma unroll
+            for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
+            if (lane < 7) {
+              const double pi = p[(size_t)7 * row + lane];
+              y += lambda * pi;
+              q[(size_t)7 * row + lane] = y;
+              pq += pi * y;
+            }
+            acc = 0.0;
+            ++row;
+            if (row - rbase >= 64) {
+              rbase += 64;
+              rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
+            }
+            k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
+          }
+          acc += vc[u] * __shfl(xgc, 7 * u + c49);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) vc[u] = vn[u];
+      xgc = xgn;
+    }
+    {  // last row of the span
+      double y = acc;
+#pragma unroll
+      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
+      if (lane < 7) {
+        const double pi = p[(size_t)7 * row + lane];
+        y += lambda * pi;
+        q[(size_t)7 * row + lane] = y;
+        pq += pi * y;
+      }
     }
   }
   const double s = block_sum(pq, sh);
@@ -593,6 +780,44 @@ __global__ __launch_bounds__(WG) void k_scale(int n, const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// HBM read calibration (bench only): streams the block-CSR value array with different access
+// shapes so the SpMV's achieved rate can be read against what this access shape can reach.
+//   mode 0: 16 B per lane, all 64 lanes, contiguous          (the copy-kernel shape)
+//   mode 1:  8 B per lane, all 64 lanes, contiguous
+//   mode 2:  8 B per lane, 49 of 64 lanes, one 392-B block per wave-instruction (SpMV shape)
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_stream_read(const double* __restrict__ src, size_t n,
+                                                    double* __restrict__ sink) {
+  double acc = 0.0;
+  const size_t tid = (size_t)blockIdx.x * WG + threadIdx.x, nth = (size_t)gridDim.x * WG;
+  if (MODE == 0) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* s2 = reinterpret_cast<const d2*>(src);
+    const size_t n2 = n / 2;
+    for (size_t i = tid; i + 3 * nth < n2; i += 4 * nth) {
+      const d2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + nth);
+      const d2 c = __builtin_nontemporal_load(s2 + i + 2 * nth), d = __builtin_nontemporal_load(s2 + i + 3 * nth);
+      acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
+    }
+  } else if (MODE == 1) {
+    for (size_t i = tid; i + 7 * nth < n; i += 8 * nth) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += __builtin_nontemporal_load(src + i + u * nth);
+    }
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int l49 = lane < 49 ? lane : lane - 49;
+    const size_t wid = tid >> 6, nw = nth >> 6, nblk = n / 49;
+    for (size_t k = wid * 8; k + 8 <= nblk; k += nw * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += __builtin_nontemporal_load(src + 49 * (k + u) + l49);
+    }
+  }
+  if (acc == 123.456) sink[0] = acc;  // keep the loads alive
+}
+
+// ------------------------------------------------------------------------------------------
 // Engine
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -622,7 +847,8 @@ class Engine {
   int32_t *d_ev0 = nullptr, *d_ev1 = nullptr, *d_hidx = nullptr, *d_active = nullptr;
   double *d_info = nullptr, *d_kdelta = nullptr;
   // system
-  int32_t *d_rowptr = nullptr, *d_colidx = nullptr, *d_incptr = nullptr;
+  int32_t *d_rowptr = nullptr, *d_colidx = nullptr, *d_incptr = nullptr, *d_wrow = nullptr;
+  int span_grid = 0;  // workgroups of the span SpMV
   int32_t *d_slot01 = nullptr, *d_slot10 = nullptr, *d_inc0 = nullptr, *d_inc1 = nullptr;
   double *d_vals = nullptr, *d_scratch = nullptr, *d_b = nullptr, *d_Minv = nullptr;
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
@@ -640,7 +866,7 @@ class Engine {
 
   void release() {
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
-                    d_rowptr, d_colidx, d_incptr, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
+                    d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
                     d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_part_a, d_part_b, d_sc};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -671,6 +897,10 @@ class Engine {
       }
       HIPCHK(hipSetDevice(opt.device));
     }
+    if (const char* ev = std::getenv("SIM3OPT_SPMV")) {
+      int a = 0, b = 0, c = 0, d = 1;
+      if (std::sscanf(ev, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) { spmv_chunk = a; spmv_nt = b; spmv_xcd = c; spmv_span = d; }  // c: bit0 XCD map, bits 4+ ablation
+    }
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
     n_active = (int32_t)s.active.size();
@@ -691,6 +921,13 @@ class Engine {
     HIPCHK(upload(d_rowptr, s.rowptr));
     HIPCHK(upload(d_colidx, s.colidx));
     HIPCHK(upload(d_incptr, s.incptr));
+    {  // span SpMV: contiguous row span per wavefront, balanced by stored blocks
+      span_grid = std::max(8, std::min(MAX_GRID, (nb + 15) / 16));
+      const int nw = span_grid * 4;
+      std::vector<int32_t> wrow(nw + 1);
+      partition_rows(nb, s.rowptr.data(), nw, wrow.data());
+      HIPCHK(upload(d_wrow, wrow));
+    }
     HIPCHK(upload(d_slot01, s.slot01));
     HIPCHK(upload(d_slot10, s.slot10));
     HIPCHK(upload(d_inc0, s.inc0));
@@ -807,16 +1044,42 @@ class Engine {
     return SIM3OPT_OK;
   }
 
+  // SpMV variant (tuning knob, env SIM3OPT_SPMV="chunk,nt,xcd"; default chosen by measurement)
+  int spmv_chunk = 8, spmv_nt = 1, spmv_xcd = 0, spmv_span = 1;
+
+  int spmv_grid() const {
+    if (spmv_span) return span_grid;
+    int g = grid_for(nb, 4);
+    return (g + 7) & ~7;  // multiple of 8: one share per XCD
+  }
+
+  void spmv_raw(double lambda, const DevScalars* scp) {
+    const int g = spmv_grid();
+    if (spmv_span) {
+#define SPAN_CASE(CH, NTV)                                                                      \
+  hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
+                     d_colidx, d_vals, d_p, d_q, lambda, d_part_a, scp)
+      if (spmv_chunk <= 4) { if (spmv_nt) SPAN_CASE(4, true); else SPAN_CASE(4, false); }
+      else { if (spmv_nt) SPAN_CASE(8, true); else SPAN_CASE(8, false); }
+#undef SPAN_CASE
+      return;
+    }
+#define SPMV_CASE(CH, NTV)                                                                    \
+  hipLaunchKernelGGL((k_spmv<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_rowptr, d_colidx, \
+                     d_vals, d_p, d_q, lambda, d_part_a, scp, spmv_xcd)
+    if (spmv_chunk <= 4) { if (spmv_nt) SPMV_CASE(4, true); else SPMV_CASE(4, false); }
+    else { if (spmv_nt) SPMV_CASE(8, true); else SPMV_CASE(8, false); }
+#undef SPMV_CASE
+  }
+
   int spmv_launch(double lambda, bool in_pcg, std::string& err) {
-    const int g = grid_for(nb, 4);
     hipEvent_t a = nullptr, b = nullptr;
     if (opt.time_kernels) {
       int rc = pool_get(a, b, err);
       if (rc) return rc;
       HIPCHK(hipEventRecord(a, stream));
     }
-    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, stream, nb, d_rowptr, d_colidx, d_vals, d_p,
-                       d_q, lambda, d_part_a, in_pcg ? d_sc : nullptr);
+    spmv_raw(lambda, in_pcg ? d_sc : nullptr);
     if (opt.time_kernels) HIPCHK(hipEventRecord(b, stream));
     return SIM3OPT_OK;
   }
@@ -825,7 +1088,7 @@ class Engine {
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
     const int gj = (nb + WG - 1) / WG;
     const int gv = grid_for((nb + 8) / 9, 4);  // 36 block rows per workgroup pass
-    const int gs = grid_for(nb, 4);
+    const int gs = spmv_grid();
     const int ge = grid_for(n, WG);
     int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
     const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
@@ -1079,17 +1342,31 @@ int engine_bench_spmv(Engine* e, int32_t reps, double* ms_mean, std::string& err
     err = "bench_spmv: call sim3opt_linearize (or optimize) first";
     return SIM3OPT_ERR_STATE;
   }
-  const int g = grid_for(e->nb, 4);
   // p = b as a representative dense vector
   HIPCHK(hipMemcpyAsync(e->d_p, e->d_b, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToDevice,
                         e->stream));
-  for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, e->stream, e->nb, e->d_rowptr, e->d_colidx,
-                       e->d_vals, e->d_p, e->d_q, 0.0, e->d_part_a, (const DevScalars*)nullptr);
+  for (int i = 0; i < 3; ++i) e->spmv_raw(0.0, nullptr);
   HIPCHK(hipEventRecord(e->ev_a, e->stream));
-  for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(WG), 0, e->stream, e->nb, e->d_rowptr, e->d_colidx,
-                       e->d_vals, e->d_p, e->d_q, 0.0, e->d_part_a, (const DevScalars*)nullptr);
+  for (int i = 0; i < reps; ++i) e->spmv_raw(0.0, nullptr);
+  HIPCHK(hipEventRecord(e->ev_b, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev_b));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev_a, e->ev_b));
+  *ms_mean = reps > 0 ? ms / reps : 0.0;
+  return SIM3OPT_OK;
+}
+
+int engine_bench_stream(Engine* e, int32_t mode, int32_t reps, double* ms_mean, std::string& err) {
+  const size_t n = (size_t)49 * (size_t)e->nnzb;
+  const int g = 2048;
+  auto launch = [&]() {
+    if (mode == 0) hipLaunchKernelGGL(k_stream_read<0>, dim3(g), dim3(WG), 0, e->stream, e->d_vals, n, e->d_q);
+    else if (mode == 1) hipLaunchKernelGGL(k_stream_read<1>, dim3(g), dim3(WG), 0, e->stream, e->d_vals, n, e->d_q);
+    else hipLaunchKernelGGL(k_stream_read<2>, dim3(g), dim3(WG), 0, e->stream, e->d_vals, n, e->d_q);
+  };
+  for (int i = 0; i < 3; ++i) launch();
+  HIPCHK(hipEventRecord(e->ev_a, e->stream));
+  for (int i = 0; i < reps; ++i) launch();
   HIPCHK(hipEventRecord(e->ev_b, e->stream));
   HIPCHK(hipEventSynchronize(e->ev_b));
   float ms = 0.f;

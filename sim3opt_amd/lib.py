@@ -100,6 +100,7 @@ SYMBOLS = {
     "sim3opt_get_system": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
+    "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
@@ -336,6 +337,11 @@ class Graph:
     def bench_spmv(self, reps=20):
         ms = C.c_double()
         self._chk(self._L.sim3opt_bench_spmv(self._g, int(reps), C.byref(ms)))
+        return ms.value
+
+    def bench_stream(self, mode, reps=20):
+        ms = C.c_double()
+        self._chk(self._L.sim3opt_bench_stream(self._g, int(mode), int(reps), C.byref(ms)))
         return ms.value
 
     # ---- reference-format I/O ----
