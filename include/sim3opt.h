@@ -167,13 +167,30 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
 
 /* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
- * Call between create and initialize.  unique_id is the 128-byte ncclUniqueId produced by
- * sim3opt_comm_unique_id on rank 0 and broadcast by the caller (torch.distributed / MPI). */
+ * Every rank adds the SAME full graph; rank r then owns a contiguous range of block rows (balanced by
+ * stored 7x7 blocks), linearises the edges incident to them, streams its rows in the SpMV and keeps
+ * a replica of all vertex estimates.  Collectives per PCG iteration: one all-gather of the search
+ * direction, two scalar all-reduces; per LM trial: one all-gather of the step, one 2-scalar
+ * all-reduce.  All ranks return identical results.  Call between create and initialize.
+ * unique_id is the 128-byte ncclUniqueId produced by sim3opt_comm_unique_id on rank 0 and broadcast
+ * by the caller (torch.distributed / MPI). */
 int sim3opt_comm_unique_id(uint8_t id_out[128]);
 int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]);
+/* Same partitioned path over user-supplied host collectives (MPI, gloo, ...): operands are staged
+ * through pinned host memory.  op: 0 = sum, 1 = max.  offsets has world+1 entries in doubles; rank r
+ * owns buf[offsets[r] .. offsets[r+1]) on entry and the whole buf must be filled on return.
+ * Callbacks return 0 on success. */
+typedef int (*sim3opt_allreduce_fn)(void* ctx, double* buf, int32_t n, int32_t op);
+typedef int (*sim3opt_allgatherv_fn)(void* ctx, double* buf, const int64_t* offsets, int32_t rank,
+                                     int32_t world);
+int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
+                                sim3opt_allreduce_fn allreduce, sim3opt_allgatherv_fn allgatherv,
+                                void* ctx);
 /* host-side partition plan (no GPU needed): first block row of each rank, size world+1 */
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin /*world+1*/);
+/* block-row range [begin, end) this graph's rank owns (valid after initialize) */
+int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end);
 
 /* ---- reference-format I/O (host C++; the callers either side of the path) ---- */
 /* Builds the graph of testDirectSim3Optimization                   kitti_surf.cpp:562-670

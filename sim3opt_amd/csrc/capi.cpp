@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/sim3opt.h"
+#include "comm.hpp"
 #include "engine.hpp"
 #include "graph.hpp"
 
@@ -21,7 +22,8 @@ struct sim3opt_graph {
   bool initialized = false;
   std::vector<sim3opt_iter_stats> stats;
   std::string err;
-  CommInfo comm;
+  Comm comm;        // handed to the engine at initialize
+  bool comm_set = false;
   ~sim3opt_graph() {
     if (engine) engine_destroy(engine);
   }
@@ -235,7 +237,9 @@ int sim3opt_initialize(sim3opt_graph* g) {
   }
   if (!build_structure(g->host, g->structure, g->err)) return SIM3OPT_ERR_STATE;
   int status = SIM3OPT_OK;
-  g->engine = engine_create(g->host, g->structure, g->opt, g->err, status);
+  g->engine = engine_create(g->host, g->structure, g->opt, g->comm_set ? &g->comm : nullptr,
+                            g->err, status);
+  g->comm_set = false;
   if (!g->engine) return status;
   g->initialized = true;
   return SIM3OPT_OK;
@@ -371,15 +375,45 @@ int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t 
 }
 
 int sim3opt_comm_unique_id(uint8_t id_out[128]) {
-  (void)id_out;
-  return SIM3OPT_ERR_COMM;  // multi-GPU transport: comm.cpp (not linked in this build)
+  if (!id_out) return SIM3OPT_ERR_ARG;
+  std::string err;
+  return comm_unique_id(id_out, err);
 }
 
 int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]) {
-  (void)unique_id;
-  if (!g) return SIM3OPT_ERR_ARG;
-  if (world == 1 && rank == 0) return SIM3OPT_OK;
-  return fail(g, SIM3OPT_ERR_COMM, "comm_init: RCCL transport not built");
+  if (!g || world < 1 || rank < 0 || rank >= world) return fail(g, SIM3OPT_ERR_ARG, "comm_init: bad rank/world");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_init: call before sim3opt_initialize");
+  if (world == 1) return SIM3OPT_OK;
+  if (!unique_id) return fail(g, SIM3OPT_ERR_ARG, "comm_init: null unique id");
+  if (g->opt.device >= 0 && hipSetDevice(g->opt.device) != hipSuccess)
+    return fail(g, SIM3OPT_ERR_HIP, "comm_init: hipSetDevice failed");
+  g->comm.release();
+  const int rc = comm_init_rccl(g->comm, rank, world, unique_id, g->err);
+  g->comm_set = rc == SIM3OPT_OK;
+  return rc;
+}
+
+int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
+                                sim3opt_allreduce_fn allreduce, sim3opt_allgatherv_fn allgatherv,
+                                void* ctx) {
+  if (!g || world < 1 || rank < 0 || rank >= world || !allreduce || !allgatherv)
+    return fail(g, SIM3OPT_ERR_ARG, "comm_init_callbacks: bad argument");
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_init_callbacks: call before sim3opt_initialize");
+  g->comm.release();
+  g->comm.rank = rank;
+  g->comm.world = world;
+  g->comm.kind = 2;
+  g->comm.cb_allreduce = allreduce;
+  g->comm.cb_allgatherv = allgatherv;
+  g->comm.cb_ctx = ctx;
+  g->comm_set = world > 1;
+  return SIM3OPT_OK;
+}
+
+int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end) {
+  if (!g || !g->initialized) return SIM3OPT_ERR_STATE;
+  engine_local_rows(g->engine, begin, end);
+  return SIM3OPT_OK;
 }
 
 }  // extern "C"

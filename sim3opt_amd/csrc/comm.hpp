@@ -1,0 +1,44 @@
+// comm.hpp -- collectives of the row-partitioned multi-GPU path (one process per GPU).
+//
+// Two transports behind one interface:
+//   RCCL      ncclAllReduce / grouped ncclBroadcast on the engine's HIP stream (xGMI); librccl is
+//             dlopen'ed at sim3opt_comm_init so that libsim3opt.so loads on machines without it
+//   callbacks host-staged: the engine copies the operands to pinned host memory and calls the
+//             user's functions (MPI, torch.distributed/gloo, ...).  Used by the 2-process tests.
+// The reference has no communication at all; this is new work.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sim3opt.h"
+
+namespace sim3opt {
+
+struct Comm {
+  int32_t rank = 0, world = 1;
+  int kind = 0;  // 0 none, 1 RCCL, 2 callbacks
+  void* nccl = nullptr;  // ncclComm_t
+  sim3opt_allreduce_fn cb_allreduce = nullptr;
+  sim3opt_allgatherv_fn cb_allgatherv = nullptr;
+  void* cb_ctx = nullptr;
+  double* h_stage = nullptr;  // pinned staging buffer (callbacks transport)
+  size_t h_stage_len = 0;
+
+  bool active() const { return world > 1; }
+  // in-place on device memory, ordered on `stream`; op: 0 = sum, 1 = max
+  int allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err);
+  // in-place all-gather of a vector split at offs[0..world] (in doubles); rank r contributes
+  // [offs[r], offs[r+1])
+  int allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
+                 std::string& err);
+  void release();
+};
+
+int comm_unique_id(uint8_t id_out[128], std::string& err);
+int comm_init_rccl(Comm& c, int32_t rank, int32_t world, const uint8_t id[128], std::string& err);
+
+}  // namespace sim3opt

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "comm.hpp"
 #include "engine.hpp"
 
 namespace sim3opt {
@@ -57,6 +58,8 @@ struct DevScalars {
   int32_t done;      // PCG finished (converged, cap reached or breakdown)
   int32_t fail;      // PCG breakdown (p.q <= 0 or non-finite) or non-SPD diagonal block
   double tol2;       // squared relative tolerance on ||r||_Minv
+  double tmp_pq;     // multi-GPU: p.q summed over ranks (all-reduced in place)
+  double tmp_rz;     // multi-GPU: r.z summed over ranks
 };
 
 // ------------------------------------------------------------------------------------------
@@ -126,7 +129,7 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho, doub
 }
 
 struct EdgeArgs {
-  int32_t ne;
+  int32_t e_lo, e_hi;  // edge range evaluated by this launch (rank's share in multi-GPU chi2)
   const int32_t* ev0;
   const int32_t* ev1;
   const Sim3* meas;
@@ -140,7 +143,7 @@ struct EdgeArgs {
 __global__ __launch_bounds__(WG) void k_chi2(EdgeArgs A, double* __restrict__ partials) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (int k = blockIdx.x * WG + threadIdx.x; k < A.ne; k += gridDim.x * WG) {
+  for (int k = A.e_lo + blockIdx.x * WG + threadIdx.x; k < A.e_hi; k += gridDim.x * WG) {
     const Sim3 C = load_sim3(A.meas + k);
     const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
     const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(WG) void k_chi2(EdgeArgs A, double* __restrict__ pa
 }
 
 __global__ __launch_bounds__(WG) void k_edge_errors(EdgeArgs A, double* __restrict__ out) {
-  for (int k = blockIdx.x * WG + threadIdx.x; k < A.ne; k += gridDim.x * WG) {
+  for (int k = A.e_lo + blockIdx.x * WG + threadIdx.x; k < A.e_hi; k += gridDim.x * WG) {
     const Sim3 C = load_sim3(A.meas + k);
     const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
     const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
 
 // One wavefront per block row: sums the per-incidence contributions in edge order, writes the
 // full symmetric diagonal block and b, tracks max |H_dd| (computeLambdaInit).
-__global__ __launch_bounds__(WG) void k_diag_reduce(int nb, const int32_t* __restrict__ incptr,
+__global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
+                                                    const int32_t* __restrict__ incptr,
                                                     const int32_t* __restrict__ rowptr,
                                                     const double* __restrict__ scratch,
                                                     double* __restrict__ vals,
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int nb, const int32_t* __res
   const int tsrc = lane < 49 ? (M * (M + 1)) / 2 + m : 0;
   const int bsrc = lane < 7 ? 28 + lane : 0;
   double dmax = 0.0;
-  for (int row = blockIdx.x * 4 + wave; row < nb; row += gridDim.x * 4) {
+  for (int row = r0 + blockIdx.x * 4 + wave; row < r1; row += gridDim.x * 4) {
     const int k0 = incptr[row], k1 = incptr[row + 1];
     double sum = 0.0;
     if (lane < 35)
@@ -356,11 +360,11 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int nb, const int32_t* __res
 // block-Jacobi preconditioner: Minv = (H_ii + lambda I)^-1, one lane per block row
 // (Gauss-Jordan without pivoting; positive pivots <=> SPD block)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_jacobi(int nb, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __restrict__ rowptr,
                                                const double* __restrict__ vals, double lambda,
                                                double* __restrict__ Minv, DevScalars* sc) {
-  const int row = blockIdx.x * WG + threadIdx.x;
-  if (row >= nb) return;
+  const int row = r0 + blockIdx.x * WG + threadIdx.x;
+  if (row >= r1) return;
   double a[7][7];
   const double* src = vals + (size_t)49 * rowptr[row];
 #pragma unroll
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
 }
 
 // x = 0, r = b, z = Minv b, p = z, partial r.z
-__global__ __launch_bounds__(WG) void k_pcg_init(int nb, const double* __restrict__ b,
+__global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* __restrict__ b,
                                                  const double* __restrict__ Minv,
                                                  double* __restrict__ x, double* __restrict__ r,
                                                  double* __restrict__ z, double* __restrict__ p,
@@ -634,9 +638,9 @@ __global__ __launch_bounds__(WG) void k_pcg_init(int nb, const double* __restric
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
   double rz = 0.0;
-  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
+  for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
     const int row = row0 + sub;
-    const bool act = lane < 63 && row < nb;
+    const bool act = lane < 63 && row < r1;
     const size_t j = (size_t)7 * row + rr;
     const double rv = act ? b[j] : 0.0;
     double zv = 0.0;
@@ -658,9 +662,9 @@ __global__ __launch_bounds__(WG) void k_pcg_init(int nb, const double* __restric
 }
 
 __global__ void k_pcg_init_final(const double* __restrict__ partials, int n, DevScalars* sc,
-                                 int max_iter, double tol2) {
+                                 int max_iter, double tol2, const double* __restrict__ scalar) {
   __shared__ double sh[4];
-  const double s = sum_partials(partials, n, sh);
+  const double s = scalar ? *scalar : sum_partials(partials, n, sh);
   if (threadIdx.x == 0) {
     sc->rz[0] = s;
     sc->rz[1] = 0.0;
@@ -674,7 +678,8 @@ __global__ void k_pcg_init_final(const double* __restrict__ partials, int n, Dev
 }
 
 // alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z
-__global__ __launch_bounds__(WG) void k_pcg_update1(int nb, int par,
+__global__ __launch_bounds__(WG) void k_pcg_update1(int r0, int r1, int par,
+                                                    const double* __restrict__ pq_scalar,
                                                     const double* __restrict__ part_pq, int npart,
                                                     const double* __restrict__ Minv,
                                                     const double* __restrict__ p,
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update1(int nb, int par,
                                                     double* __restrict__ part_rz, DevScalars* sc) {
   __shared__ double sh[4];
   if (sc->done) return;
-  const double pq = sum_partials(part_pq, npart, sh);
+  const double pq = pq_scalar ? *pq_scalar : sum_partials(part_pq, npart, sh);
   if (!(pq > 0.0) || !(pq < DBL_MAX)) {  // breakdown: not SPD or non-finite
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       sc->fail = 1;
@@ -697,9 +702,9 @@ __global__ __launch_bounds__(WG) void k_pcg_update1(int nb, int par,
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
   double rz = 0.0;
-  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
+  for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
     const int row = row0 + sub;
-    const bool act = lane < 63 && row < nb;
+    const bool act = lane < 63 && row < r1;
     const size_t j = (size_t)7 * row + rr;
     double rv = 0.0;
     if (act) {
@@ -724,15 +729,17 @@ __global__ __launch_bounds__(WG) void k_pcg_update1(int nb, int par,
 
 // beta = rz_new / rz ; p = z + beta p ; workgroup 0 commits rz_new, the iteration count and the
 // stopping decision for the NEXT launches.
-__global__ __launch_bounds__(WG) void k_pcg_update2(int n, int par,
+__global__ __launch_bounds__(WG) void k_pcg_update2(int j0, int j1, int par,
+                                                    const double* __restrict__ rz_scalar,
                                                     const double* __restrict__ part_rz, int npart,
                                                     const double* __restrict__ z,
                                                     double* __restrict__ p, DevScalars* sc) {
   __shared__ double sh[4];
   if (sc->done) return;
-  const double rz_new = sum_partials(part_rz, npart, sh);
+  const double rz_new = rz_scalar ? *rz_scalar : sum_partials(part_rz, npart, sh);
   const double beta = rz_new / sc->rz[par];
-  for (int j = blockIdx.x * WG + threadIdx.x; j < n; j += gridDim.x * WG) p[j] = z[j] + beta * p[j];
+  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
+    p[j] = z[j] + beta * p[j];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sc->rz[par ^ 1] = rz_new;
     const int it = sc->iter + 1;
@@ -768,12 +775,12 @@ __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict_
 }
 
 // computeScale: sum_j x_j (lambda x_j + b_j)
-__global__ __launch_bounds__(WG) void k_scale(int n, const double* __restrict__ x,
+__global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
                                               const double* __restrict__ b, double lambda,
                                               double* __restrict__ partials) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (int j = blockIdx.x * WG + threadIdx.x; j < n; j += gridDim.x * WG)
+  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
     acc += x[j] * (lambda * x[j] + b[j]);
   const double s = block_sum(acc, sh);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -856,6 +863,11 @@ class Engine {
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool linearized = false;
+  // multi-GPU row partition: this rank owns block rows [r0, r1); offs = 7 * row_begin
+  Comm comm;
+  int32_t r0 = 0, r1 = 0, e_lo = 0, e_hi = 0;
+  std::vector<int32_t> row_begin;
+  std::vector<int64_t> offs;
   // timing
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> pool;  // pairs (start, stop) for per-launch SpMV timing
@@ -875,12 +887,13 @@ class Engine {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (stream) (void)hipStreamDestroy(stream);
+    comm.release();
   }
 
   sim3::Opts mopts() const { return sim3::Opts{opt.exp_eps, opt.small_rot_half, opt.fix_small_angle_b}; }
 
   EdgeArgs edge_args() const {
-    return EdgeArgs{ne, d_ev0, d_ev1, d_meas, has_info ? d_info : nullptr,
+    return EdgeArgs{e_lo, e_hi, d_ev0, d_ev1, d_meas, has_info ? d_info : nullptr,
                     has_kernel ? d_kdelta : nullptr, d_states, mopts()};
   }
 
@@ -903,7 +916,29 @@ class Engine {
     }
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
-    n_active = (int32_t)s.active.size();
+    // row partition (world == 1: everything is local)
+    row_begin.assign(comm.world + 1, 0);
+    partition_rows(nb, s.rowptr.data(), comm.world, row_begin.data());
+    r0 = row_begin[comm.rank];
+    r1 = row_begin[comm.rank + 1];
+    offs.resize(comm.world + 1);
+    for (int r = 0; r <= comm.world; ++r) offs[r] = 7 * (int64_t)row_begin[r];
+    e_lo = (int32_t)((int64_t)ne * comm.rank / comm.world);
+    e_hi = (int32_t)((int64_t)ne * (comm.rank + 1) / comm.world);
+    // this rank linearises the edges incident to its rows and writes only its rows' blocks
+    std::vector<int32_t> l_active, l_s01 = s.slot01, l_s10 = s.slot10, l_i0 = s.inc0, l_i1 = s.inc1;
+    if (comm.world > 1) {
+      for (int32_t k : s.active) {
+        const int32_t a = s.hidx[g.ev0[k]], b = s.hidx[g.ev1[k]];
+        const bool la = a >= r0 && a < r1, lb = b >= r0 && b < r1;
+        if (!la) { l_s01[k] = -1; l_i0[k] = -1; }
+        if (!lb) { l_s10[k] = -1; l_i1[k] = -1; }
+        if (la || lb) l_active.push_back(k);
+      }
+    } else {
+      l_active = s.active;
+    }
+    n_active = (int32_t)l_active.size();
     has_info = g.has_info;
     has_kernel = g.has_kernel;
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -915,23 +950,25 @@ class Engine {
     HIPCHK(upload(d_ev0, g.ev0));
     HIPCHK(upload(d_ev1, g.ev1));
     HIPCHK(upload(d_hidx, s.hidx));
-    HIPCHK(upload(d_active, s.active));
+    HIPCHK(upload(d_active, l_active));
     if (has_info) HIPCHK(upload(d_info, g.info));
     if (has_kernel) HIPCHK(upload(d_kdelta, g.kdelta));
     HIPCHK(upload(d_rowptr, s.rowptr));
     HIPCHK(upload(d_colidx, s.colidx));
     HIPCHK(upload(d_incptr, s.incptr));
     {  // span SpMV: contiguous row span per wavefront, balanced by stored blocks
-      span_grid = std::max(8, std::min(MAX_GRID, (nb + 15) / 16));
+      const int nloc = r1 - r0;
+      span_grid = std::max(8, std::min(MAX_GRID, (nloc + 15) / 16));
       const int nw = span_grid * 4;
       std::vector<int32_t> wrow(nw + 1);
-      partition_rows(nb, s.rowptr.data(), nw, wrow.data());
+      partition_rows(nloc, s.rowptr.data() + r0, nw, wrow.data());
+      for (int32_t& w : wrow) w += r0;
       HIPCHK(upload(d_wrow, wrow));
     }
-    HIPCHK(upload(d_slot01, s.slot01));
-    HIPCHK(upload(d_slot10, s.slot10));
-    HIPCHK(upload(d_inc0, s.inc0));
-    HIPCHK(upload(d_inc1, s.inc1));
+    HIPCHK(upload(d_slot01, l_s01));
+    HIPCHK(upload(d_slot10, l_s10));
+    HIPCHK(upload(d_inc0, l_i0));
+    HIPCHK(upload(d_inc1, l_i1));
     HIPCHK(hipMalloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
     HIPCHK(hipMemset(d_vals, 0, sizeof(double) * 49 * (size_t)nnzb));
     const size_t ninc = (size_t)s.incptr[nb];
@@ -1006,11 +1043,16 @@ class Engine {
 
   // ---- building blocks ----
   int chi2(double* out, std::string& err) {
-    const int g = grid_for(ne, WG);
+    const int g = grid_for(e_hi - e_lo, WG);
     hipLaunchKernelGGL(k_chi2, dim3(g), dim3(WG), 0, stream, edge_args(), d_part_a);
     hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
     HIPCHK(hipGetLastError());
-    int rc = fetch_scalars(err);
+    int rc = SIM3OPT_OK;
+    if (comm.active()) {  // chi2 and scale are adjacent: one 2-double all-reduce per LM trial
+      rc = comm.allreduce(&d_sc->chi2, 2, 0, stream, err);
+      if (rc) return rc;
+    }
+    rc = fetch_scalars(err);
     if (rc) return rc;
     *out = h_sc->chi2;
     kt.n_chi2 += 1;
@@ -1036,9 +1078,13 @@ class Engine {
       else
         hipLaunchKernelGGL((k_linearize_numeric<false, false>), dim3(g), dim3(WG), 0, stream, A);
     }
-    hipLaunchKernelGGL(k_diag_reduce, dim3(grid_for(nb, 4)), dim3(WG), 0, stream, nb, d_incptr,
-                       d_rowptr, d_scratch, d_vals, d_b, d_sc);
+    hipLaunchKernelGGL(k_diag_reduce, dim3(grid_for(r1 - r0, 4)), dim3(WG), 0, stream, r0, r1,
+                       d_incptr, d_rowptr, d_scratch, d_vals, d_b, d_sc);
     HIPCHK(hipGetLastError());
+    if (comm.active()) {  // non-negative doubles order like their bit patterns
+      int rc = comm.allreduce(reinterpret_cast<double*>(&d_sc->maxdiag_bits), 1, 1, stream, err);
+      if (rc) return rc;
+    }
     linearized = true;
     kt.n_linearize += 1;
     return SIM3OPT_OK;
@@ -1048,14 +1094,14 @@ class Engine {
   int spmv_chunk = 8, spmv_nt = 1, spmv_xcd = 0, spmv_span = 1;
 
   int spmv_grid() const {
-    if (spmv_span) return span_grid;
+    if (spmv_span || comm.active()) return span_grid;
     int g = grid_for(nb, 4);
     return (g + 7) & ~7;  // multiple of 8: one share per XCD
   }
 
   void spmv_raw(double lambda, const DevScalars* scp) {
     const int g = spmv_grid();
-    if (spmv_span) {
+    if (spmv_span || comm.active()) {
 #define SPAN_CASE(CH, NTV)                                                                      \
   hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
                      d_colidx, d_vals, d_p, d_q, lambda, d_part_a, scp)
@@ -1086,24 +1132,36 @@ class Engine {
 
   // block-Jacobi PCG on (H + lambda I) x = b; result stays in d_x.
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
-    const int gj = (nb + WG - 1) / WG;
-    const int gv = grid_for((nb + 8) / 9, 4);  // 36 block rows per workgroup pass
+    const int nloc = r1 - r0;
+    const int gj = std::max(1, (nloc + WG - 1) / WG);
+    const int gv = grid_for((nloc + 8) / 9, 4);  // 36 block rows per workgroup pass
     const int gs = spmv_grid();
-    const int ge = grid_for(n, WG);
+    const int ge = grid_for(7 * (int64_t)nloc, WG);
+    const bool multi = comm.active();
+    const double* pq_s = multi ? &d_sc->tmp_pq : nullptr;
+    const double* rz_s = multi ? &d_sc->tmp_rz : nullptr;
     int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
     const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
+    int rc = SIM3OPT_OK;
     HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, nb, d_rowptr, d_vals, lambda,
+    hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, r0, r1, d_rowptr, d_vals, lambda,
                        d_Minv, d_sc);
-    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, nb, d_b, d_Minv, d_x, d_r, d_z,
-                       d_p, d_part_b);
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, d_Minv, d_x, d_r,
+                       d_z, d_p, d_part_b);
+    if (multi) {
+      hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gv, &d_sc->tmp_rz);
+      rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
+      if (rc) return rc;
+      rc = comm.allgatherv(d_p, offs, stream, err);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(WG), 0, stream, d_part_b, gv, d_sc, max_it,
-                       tol2);
+                       tol2, rz_s);
     HIPCHK(hipGetLastError());
     const int chunk = std::max(1, opt.pcg_check_every);
     int it = 0, par = 0;
     for (;;) {
-      int rc = fetch_scalars(err);
+      rc = fetch_scalars(err);
       if (rc) return rc;
       if (opt.time_kernels) {
         rc = pool_drain(err);
@@ -1114,14 +1172,34 @@ class Engine {
       for (int c = 0; c < todo; ++c) {
         rc = spmv_launch(lambda, true, err);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_pcg_update1, dim3(gv), dim3(WG), 0, stream, nb, par, d_part_a, gs,
-                           d_Minv, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
-        hipLaunchKernelGGL(k_pcg_update2, dim3(ge), dim3(WG), 0, stream, n, par, d_part_b, gv,
-                           d_z, d_p, d_sc);
+        if (multi) {
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gs,
+                             &d_sc->tmp_pq);
+          rc = comm.allreduce(&d_sc->tmp_pq, 1, 0, stream, err);
+          if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_pcg_update1, dim3(gv), dim3(WG), 0, stream, r0, r1, par, pq_s,
+                           d_part_a, gs, d_Minv, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
+        if (multi) {
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gv,
+                             &d_sc->tmp_rz);
+          rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
+          if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_pcg_update2, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, par, rz_s,
+                           d_part_b, gv, d_z, d_p, d_sc);
+        if (multi) {
+          rc = comm.allgatherv(d_p, offs, stream, err);
+          if (rc) return rc;
+        }
         par ^= 1;
         ++it;
       }
       HIPCHK(hipGetLastError());
+    }
+    if (multi) {  // every rank updates its replica of all estimates
+      rc = comm.allgatherv(d_x, offs, stream, err);
+      if (rc) return rc;
     }
     kt.n_pcg_vec += h_sc->iter;
     *iters = h_sc->iter;
@@ -1180,9 +1258,9 @@ class Engine {
         if (ok2) {
           hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
                              d_x, d_states, mopts());
-          const int ge = grid_for(n, WG);
-          hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, n, d_x, d_b, lambda,
-                             d_part_b);
+          const int ge = grid_for(7 * (int64_t)(r1 - r0), WG);
+          hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
+                             lambda, d_part_b);
           hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, ge,
                              &d_sc->scale);
           HIPCHK(hipGetLastError());
@@ -1236,9 +1314,13 @@ class Engine {
 // C++ interface used by capi.cpp
 // ------------------------------------------------------------------------------------------
 Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_options& opt,
-                      std::string& err, int& status) {
+                      Comm* comm, std::string& err, int& status) {
   Engine* e = new Engine();
   e->opt = opt;
+  if (comm) {  // the engine takes the communicator over
+    e->comm = *comm;
+    *comm = Comm();
+  }
   status = e->init(g, s, err);
   if (status != SIM3OPT_OK) {
     delete e;
@@ -1279,8 +1361,10 @@ int engine_set_states(Engine* e, const Sim3* in, std::string& err) {
 int engine_edge_errors(Engine* e, double* out, std::string& err) {
   double* d_out = nullptr;
   HIPCHK(hipMalloc((void**)&d_out, sizeof(double) * 7 * std::max<size_t>((size_t)e->ne, 1)));
-  hipLaunchKernelGGL(k_edge_errors, dim3(grid_for(e->ne, WG)), dim3(WG), 0, e->stream,
-                     e->edge_args(), d_out);
+  EdgeArgs ea = e->edge_args();
+  ea.e_lo = 0;
+  ea.e_hi = e->ne;
+  hipLaunchKernelGGL(k_edge_errors, dim3(grid_for(e->ne, WG)), dim3(WG), 0, e->stream, ea, d_out);
   hipError_t le = hipGetLastError();
   if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
   if (le == hipSuccess)
@@ -1373,6 +1457,11 @@ int engine_bench_stream(Engine* e, int32_t mode, int32_t reps, double* ms_mean, 
   HIPCHK(hipEventElapsedTime(&ms, e->ev_a, e->ev_b));
   *ms_mean = reps > 0 ? ms / reps : 0.0;
   return SIM3OPT_OK;
+}
+
+void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end) {
+  if (begin) *begin = e->r0;
+  if (end) *end = e->r1;
 }
 
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {

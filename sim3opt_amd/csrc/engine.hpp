@@ -16,15 +16,12 @@ namespace sim3opt {
 
 class Engine;  // opaque, defined in engine.hip
 
+struct Comm;
+// comm (may be null) is moved into the engine
 Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_options& opt,
-                      std::string& err, int& status);
+                      Comm* comm, std::string& err, int& status);
+void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end);
 void engine_destroy(Engine* e);
-
-// multi-GPU: attach an RCCL communicator before engine_create (comm.cpp)
-struct CommInfo {
-  int32_t rank = 0, world = 1;
-  void* nccl_comm = nullptr;  // ncclComm_t
-};
 
 int engine_set_options(Engine* e, const sim3opt_options& opt);
 int engine_optimize(Engine* e, int32_t max_iters, std::vector<sim3opt_iter_stats>& stats,

@@ -95,12 +95,12 @@ bool build_structure(const HostGraph& g, Structure& s, std::string& err) {
 
 void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin) {
   // split so that every rank streams about the same number of 7x7 blocks per SpMV
-  const int64_t total = rowptr[nb];
+  const int64_t base = rowptr[0], total = (int64_t)rowptr[nb] - base;  // rowptr may be a sub-range
   begin[0] = 0;
   int32_t row = 0;
   for (int32_t r = 1; r < world; ++r) {
     const int64_t target = total * r / world;
-    while (row < nb && rowptr[row] < target) ++row;
+    while (row < nb && (int64_t)rowptr[row] - base < target) ++row;
     begin[r] = row;
   }
   begin[world] = nb;

@@ -103,6 +103,8 @@ SYMBOLS = {
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
+    "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
@@ -125,6 +127,10 @@ def load():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int32, C.c_int32)
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
 
 
 class Sim3OptError(RuntimeError):
@@ -238,6 +244,44 @@ class Graph:
         m = np.empty(8)
         self._chk(self._L.sim3opt_get_edge(self._g, int(k), C.byref(a), C.byref(b), _p(m, _dp)))
         return a.value, b.value, m
+
+    # ---- multi-GPU ----
+    def comm_init_rccl(self, rank, world, unique_id):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.shape == (128,)
+        self._chk(self._L.sim3opt_comm_init(self._g, int(rank), int(world), _p(uid, _up)))
+
+    def comm_init_callbacks(self, rank, world, allreduce, allgatherv):
+        """allreduce(np_array, op) and allgatherv(np_array, offsets, rank) operate IN PLACE on
+        numpy views of the library's pinned host staging buffer."""
+        def _ar(ctx, buf, n, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(n,)), int(op))
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ag(ctx, buf, offs, rk, world_):
+            try:
+                o = np.ctypeslib.as_array(offs, shape=(world_ + 1,))
+                allgatherv(np.ctypeslib.as_array(buf, shape=(int(o[-1]),)), o, int(rk))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb_refs = (ALLREDUCE_FN(_ar), ALLGATHERV_FN(_ag))  # keep alive
+        self._chk(self._L.sim3opt_comm_init_callbacks(
+            self._g, int(rank), int(world), C.cast(self._cb_refs[0], C.c_void_p),
+            C.cast(self._cb_refs[1], C.c_void_p), None))
+
+    def local_rows(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self._L.sim3opt_local_rows(self._g, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # ---- optimisation ----
     def initialize(self):
