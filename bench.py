@@ -43,6 +43,10 @@ def parse():
                          "lambda ~1e8, reported separately as reference_arithmetic")
     ap.add_argument("--pcg-rel-tol", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
+                    help="multi-rank collectives: rccl (default; ncclAllReduce / grouped ncclBroadcast "
+                         "on the library's stream) or gloo (host-staged callbacks; lets N ranks share "
+                         "one GPU for dry runs)")
     ap.add_argument("--cpu-sample-vertices", type=int, default=1000)
     return ap.parse_args()
 
@@ -93,12 +97,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    if args.transport == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.transport == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sim3opt_amd import build as B, lib as L, synth
     B.build()
@@ -110,7 +119,19 @@ def main():
                 fix_small_angle_b=args.fix_small_angle_b)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
-    if world > 1:
+    if world > 1 and args.transport == "gloo":
+        def _ar(arr, op):
+            dist.all_reduce(torch.from_numpy(arr),
+                            op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+
+        def _ag(arr, offs, rk):
+            t = torch.from_numpy(arr)
+            for r in range(len(offs) - 1):
+                if offs[r + 1] > offs[r]:
+                    dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r)
+
+        G.comm_init_callbacks(rank, world, _ar, _ag)
+    elif world > 1:
         uid = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             rc = L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up))
@@ -118,7 +139,7 @@ def main():
                 raise SystemExit("sim3opt_comm_unique_id failed")
         t = torch.from_numpy(uid).cuda()
         dist.broadcast(t, 0)
-        uid = t.cpu().numpy()
+        uid = np.ascontiguousarray(t.cpu().numpy())
         rc = L.load().sim3opt_comm_init(G._g, rank, world, uid.ctypes.data_as(L._up))
         if rc != L.OK:
             raise SystemExit("sim3opt_comm_init: " + L.load().sim3opt_last_error(G._g).decode())
@@ -156,7 +177,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64,
+                          device="cpu" if args.transport == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kt = G.kernel_times()
@@ -166,7 +188,8 @@ def main():
         K = args.steps
         # algorithmic bytes of one SpMV launch: blocks + column indices + row
         # pointers, p read once, q written once; per rank when row-partitioned
-        rows_local = nb if world == 1 else (nb + world - 1) // world
+        lo, hi = G.local_rows()  # rank 0's share (ranks are balanced by stored blocks)
+        rows_local = hi - lo
         blocks_local = nnzb if world == 1 else (nnzb + world - 1) // world
         spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 2 * 7 * rows_local * 8
         roof = None
@@ -188,7 +211,8 @@ def main():
                                    f"rel tol {args.pcg_rel_tol:g}",
                        "vertices": args.vertices, "edges": args.edges,
                        "fix_small_angle_b": args.fix_small_angle_b,
-                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world}"},
+                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world}",
+                       "transport": None if world == 1 else args.transport},
             "edges_iters_per_s": args.edges * K / dt,
             "chi2_initial": chi2_0, "chi2_final": chi2_final,
             "lm_trials": [int(s.trials) for s in stats],

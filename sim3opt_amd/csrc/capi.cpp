@@ -1,6 +1,7 @@
 // capi.cpp -- the C-ABI of libsim3opt (include/sim3opt.h): argument checking, the host graph
 // container and dispatch into the HIP engine.  No exceptions leave this file.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -383,12 +384,17 @@ int sim3opt_comm_unique_id(uint8_t id_out[128]) {
 int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]) {
   if (!g || world < 1 || rank < 0 || rank >= world) return fail(g, SIM3OPT_ERR_ARG, "comm_init: bad rank/world");
   if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_init: call before sim3opt_initialize");
-  if (world == 1) return SIM3OPT_OK;
+  // SIM3OPT_FORCE_COMM=1: build the communicator and run every collective even with one rank
+  // (self-test of the RCCL transport on a single-GPU machine)
+  const char* fc = std::getenv("SIM3OPT_FORCE_COMM");
+  const bool force = fc && fc[0] == '1';
+  if (world == 1 && !force) return SIM3OPT_OK;
   if (!unique_id) return fail(g, SIM3OPT_ERR_ARG, "comm_init: null unique id");
   if (g->opt.device >= 0 && hipSetDevice(g->opt.device) != hipSuccess)
     return fail(g, SIM3OPT_ERR_HIP, "comm_init: hipSetDevice failed");
   g->comm.release();
   const int rc = comm_init_rccl(g->comm, rank, world, unique_id, g->err);
+  g->comm.force = force;
   g->comm_set = rc == SIM3OPT_OK;
   return rc;
 }

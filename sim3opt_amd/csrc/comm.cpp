@@ -114,7 +114,7 @@ static int ensure_stage(Comm& c, size_t n, std::string& err) {
 }
 
 int Comm::allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err) {
-  if (world <= 1) return SIM3OPT_OK;
+  if (!active()) return SIM3OPT_OK;
   if (kind == 1) {
     NCCLCHK(g_api.AllReduce(dptr, dptr, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum,
                             (ncclComm_t)nccl, stream));
@@ -135,7 +135,7 @@ int Comm::allreduce(double* dptr, int n, int op, hipStream_t stream, std::string
 
 int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
                      std::string& err) {
-  if (world <= 1) return SIM3OPT_OK;
+  if (!active()) return SIM3OPT_OK;
   if (kind == 1) {
     // ranks own unequal spans (balanced by stored blocks), so one grouped broadcast per owner
     NCCLCHK(g_api.GroupStart());
@@ -179,6 +179,7 @@ void Comm::release() {
   kind = 0;
   world = 1;
   rank = 0;
+  force = false;
 }
 
 }  // namespace sim3opt

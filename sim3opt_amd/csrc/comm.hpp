@@ -28,7 +28,8 @@ struct Comm {
   double* h_stage = nullptr;  // pinned staging buffer (callbacks transport)
   size_t h_stage_len = 0;
 
-  bool active() const { return world > 1; }
+  bool force = false;  // run the collectives even with one rank (transport self-test)
+  bool active() const { return world > 1 || force; }
   // in-place on device memory, ordered on `stream`; op: 0 = sum, 1 = max
   int allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err);
   // in-place all-gather of a vector split at offs[0..world] (in doubles); rank r contributes

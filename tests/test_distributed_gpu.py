@@ -74,3 +74,33 @@ def test_two_process_row_partition_matches_single(tmp_path, world):
         # vs the single-process run: only summation order differs
         assert np.allclose(r["chi"], [s.chi2_after for s in st], rtol=1e-7)
         assert synth.rmse(r["states"], G.get_vertices()) < 1e-6
+
+
+def test_rccl_transport_single_rank_selftest(monkeypatch):
+    """The RCCL transport (dlopen, ncclCommInitRank, in-place ncclAllReduce, grouped in-place
+    ncclBroadcast on the engine's stream) exercised with one rank: every collective of the
+    multi-GPU branch runs and must reproduce the plain single-GPU result bit for bit."""
+    import ctypes as C
+    from sim3opt_amd import lib as L
+    monkeypatch.setenv("SIM3OPT_FORCE_COMM", "1")
+    g = _graph()
+    uid = np.zeros(128, dtype=np.uint8)
+    assert L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) == L.OK
+    assert uid.any()
+    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10)
+    A.add_vertices(g["states"], g["fixed"])
+    A.add_edges(g["v0"], g["v1"], g["meas"])
+    A.comm_init_rccl(0, 1, uid)
+    A.initialize()
+    A.optimize(3)
+    monkeypatch.delenv("SIM3OPT_FORCE_COMM")
+    B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10)
+    B.add_vertices(g["states"], g["fixed"])
+    B.add_edges(g["v0"], g["v1"], g["meas"])
+    B.initialize()
+    B.optimize(3)
+    assert [s.trials for s in A.stats()] == [s.trials for s in B.stats()]
+    assert np.allclose([s.chi2_after for s in A.stats()], [s.chi2_after for s in B.stats()],
+                       rtol=1e-9)
+    from sim3opt_amd import synth
+    assert synth.rmse(A.get_vertices(), B.get_vertices()) < 1e-7
