@@ -192,12 +192,21 @@ def main():
         rows_local = hi - lo
         blocks_local = nnzb if world == 1 else (nnzb + world - 1) // world
         spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 2 * 7 * rows_local * 8
+        # HBM bytes per SpMV launch from the last rocprofv3 --pmc collection (separate passes;
+        # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r1_pmc_spmv.json
+        traffic = None
+        try:
+            if world == 1 and args.vertices == 100000 and args.edges == 1000000:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_spmv.json")))
+                traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
+        except Exception:
+            traffic = None
         roof = None
         if kt.n_spmv > 0:
             avg_ms = kt.ms_spmv / kt.n_spmv
             ach = spmv_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_spmv", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_ms": avg_ms, "launches": int(kt.n_spmv),
                     "algorithmic_bytes_per_launch": int(spmv_bytes)}
         out = {
