@@ -21,6 +21,7 @@ struct sim3opt_graph {
   sim3opt_options opt;
   Engine* engine = nullptr;
   bool initialized = false;
+  bool dirty = false;  // vertices/edges added since the last initialize (g2o: re-initialize)
   std::vector<sim3opt_iter_stats> stats;
   std::string err;
   Comm comm;        // handed to the engine at initialize
@@ -161,7 +162,7 @@ const char* sim3opt_last_error(const sim3opt_graph* g) { return g ? g->err.c_str
 
 int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int32_t fixed) {
   if (!g || !state) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: null argument");
-  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_vertex: graph already initialized");
+  if (g->initialized) g->dirty = true;  // needs initializeOptimization() again, like g2o
   if (!state_ok(state)) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: non-finite state or scale <= 0");
   HostGraph& h = g->host;
   if (!h.id2idx.emplace(id, (int32_t)h.vid.size()).second)
@@ -175,7 +176,6 @@ int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int3
 int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids, const double* states,
                          const uint8_t* fixed) {
   if (!g || n < 0 || (n > 0 && !states)) return fail(g, SIM3OPT_ERR_ARG, "add_vertices: bad argument");
-  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_vertices: graph already initialized");
   HostGraph& h = g->host;
   h.vid.reserve(h.vid.size() + n);
   h.states.reserve(h.states.size() + n);
@@ -193,7 +193,7 @@ int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids, const 
 int sim3opt_add_edge(sim3opt_graph* g, int32_t id_v0, int32_t id_v1, const double meas[8],
                      const double* info77, int32_t kernel, double kernel_delta) {
   if (!g || !meas) return fail(g, SIM3OPT_ERR_ARG, "add_edge: null argument");
-  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_edge: graph already initialized");
+  if (g->initialized) g->dirty = true;
   return add_edge_impl(g, id_v0, id_v1, meas, info77, kernel, kernel_delta);
 }
 
@@ -202,7 +202,7 @@ int sim3opt_add_edges(sim3opt_graph* g, int32_t m, const int32_t* id_v0, const i
                       double kernel_delta) {
   if (!g || m < 0 || (m > 0 && (!id_v0 || !id_v1 || !meas)))
     return fail(g, SIM3OPT_ERR_ARG, "add_edges: bad argument");
-  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "add_edges: graph already initialized");
+  if (g->initialized) g->dirty = true;
   HostGraph& h = g->host;
   h.ev0.reserve(h.ev0.size() + m);
   h.ev1.reserve(h.ev1.size() + m);
@@ -235,6 +235,7 @@ int sim3opt_initialize(sim3opt_graph* g) {
     engine_destroy(g->engine);
     g->engine = nullptr;
     g->initialized = false;
+    g->dirty = false;
   }
   if (!build_structure(g->host, g->structure, g->err)) return SIM3OPT_ERR_STATE;
   int status = SIM3OPT_OK;
@@ -255,6 +256,7 @@ int sim3opt_optimize(sim3opt_graph* g, int32_t max_iters) {
     return 0;
   }
   if (max_iters <= 0) return 0;
+  if (g->dirty) { g->err = "optimize: graph changed, call sim3opt_initialize again"; return 0; }
   const int rc = engine_optimize(g->engine, max_iters, g->stats, g->err);
   return rc < 0 ? 0 : rc;
 }
@@ -300,7 +302,7 @@ int sim3opt_set_vertices(sim3opt_graph* g, const double* states) {
 
 int sim3opt_chi2(sim3opt_graph* g, double* chi2) {
   if (!g || !chi2) return fail(g, SIM3OPT_ERR_ARG, "chi2: null argument");
-  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "chi2: call sim3opt_initialize first");
+  if (!g->initialized || g->dirty) return fail(g, SIM3OPT_ERR_STATE, "chi2: call sim3opt_initialize first");
   return engine_chi2(g->engine, chi2, g->err);
 }
 
@@ -326,13 +328,13 @@ int sim3opt_reset_kernel_times(sim3opt_graph* g) {
 
 int sim3opt_edge_errors(sim3opt_graph* g, double* e_out) {
   if (!g || !e_out) return fail(g, SIM3OPT_ERR_ARG, "edge_errors: null argument");
-  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "edge_errors: call sim3opt_initialize first");
+  if (!g->initialized || g->dirty) return fail(g, SIM3OPT_ERR_STATE, "edge_errors: call sim3opt_initialize first");
   return engine_edge_errors(g->engine, e_out, g->err);
 }
 
 int sim3opt_linearize(sim3opt_graph* g) {
   if (!g) return SIM3OPT_ERR_ARG;
-  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "linearize: call sim3opt_initialize first");
+  if (!g->initialized || g->dirty) return fail(g, SIM3OPT_ERR_STATE, "linearize: call sim3opt_initialize first");
   return engine_linearize(g->engine, g->err);
 }
 
