@@ -200,6 +200,14 @@ int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one
  * precision: 17 significant digits (the reference prints 6). image_ids may be NULL. */
 int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids);
 
+/* ---- evaluation harness (host C++) ----
+ * estimateSimilarityTransform = Eigen::umeyama(query, train, true)   kitti_surf.cpp:1091-1161
+ * followed by the RMSE / max deviation of the aligned positions      kitti_surf.cpp:1446-1463.
+ * S is the 4x4 row-major similarity [cR t; 0 1] mapping query to train coordinates. */
+int sim3opt_align_trajectory(int32_t n, const double* query_xyz /*n x 3*/,
+                             const double* train_xyz /*n x 3*/, int32_t with_scale, double S[16],
+                             double* rmse, double* max_dev);
+
 #ifdef __cplusplus
 }
 #endif

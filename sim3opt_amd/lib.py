@@ -108,6 +108,7 @@ SYMBOLS = {
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
+    "sim3opt_align_trajectory": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _dp]),
 }
 
 _lib = None
@@ -396,6 +397,18 @@ class Graph:
     def write_poses(self, path, image_ids=None):
         ids = None if image_ids is None else _i32(image_ids)
         self._chk(self._L.sim3opt_write_poses(self._g, os.fsencode(path), _p(ids, _ip)))
+
+
+def align_trajectory(query_xyz, train_xyz, with_scale=True):
+    """(S 4x4, rmse, max_dev) of the Umeyama alignment query -> train (kitti_surf.cpp:1091-1161)."""
+    q, t = _f64(query_xyz).reshape(-1, 3), _f64(train_xyz).reshape(-1, 3)
+    S = np.empty(16)
+    rm, mx = C.c_double(), C.c_double()
+    rc = load().sim3opt_align_trajectory(q.shape[0], _p(q, _dp), _p(t, _dp), int(with_scale),
+                                         _p(S, _dp), C.byref(rm), C.byref(mx))
+    if rc != OK:
+        raise Sim3OptError(rc, "align_trajectory")
+    return S.reshape(4, 4), rm.value, mx.value
 
 
 def partition_rows(rowptr, world):

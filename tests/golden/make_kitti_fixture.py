@@ -5,6 +5,8 @@ Run in the build container only (needs /root/reference/data).  Copies data files
   loopConstraints.txt  -- 118 loop constraints          (read by kitti_surf.cpp:145-205)
   framePoses_kf.txt    -- the 2 header lines + only the 771 keyframe rows of framePoses.txt
                           (kitti_surf.cpp:255-292 keeps exactly these rows)
+  gt_kf.txt            -- the 771 keyframe rows of 00.txt (KITTI ground truth; kitti_surf.cpp:1427-1440
+                          keeps exactly these rows for the RMSE evaluation)
 """
 import os
 import shutil
@@ -25,4 +27,11 @@ with open(os.path.join(SRC, "framePoses.txt")) as f, \
         if ln.strip() and int(ln.split(",")[0]) in ids:
             g.write(ln + "\n")
             n += 1
+# ground truth of the keyframes only (00.txt: 4541 rows of 3x4 Pc2w; kitti_surf.cpp:1164-1190, :1427-1440)
+gt = open(os.path.join(SRC, "00.txt")).read().splitlines()
+with open(os.path.join(DST, "gt_kf.txt"), "w") as g:
+    g.write("% KITTI odometry 00 ground truth rows (3x4 Pc2w, row-major) of the 771 keyframes: image id "
+            "+ 12 values; from data/map000000/00.txt (read at kitti_surf.cpp:1164-1190)\n")
+    for i in sorted(ids):
+        g.write(str(i) + " " + gt[i].strip() + "\n")
 print("keyframes", len(ids), "rows kept", n)

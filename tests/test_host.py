@@ -146,3 +146,45 @@ def test_partition_rows_balances_blocks():
         assert max(loads) - min(loads) <= 2 * deg.max()
     beg = L.partition_rows(np.array([0, 5], dtype=np.int32), 4)  # fewer rows than ranks
     assert beg[0] == 0 and beg[-1] == 1 and np.all(np.diff(beg) >= 0)
+
+
+def test_umeyama_alignment_and_kitti_original_map_rmse():
+    """Evaluation harness (kitti_surf.cpp:1091-1161, :1427-1463): C++ Umeyama vs numpy SVD, and
+    the RMSE of the un-optimised VO keyframe trajectory against KITTI-00 ground truth."""
+    def umeyama_np(x, y):
+        mx, my = x.mean(0), y.mean(0)
+        dx, dy = x - mx, y - my
+        U, D, Vt = np.linalg.svd(dy.T @ dx / len(x))
+        Sg = np.eye(3)
+        if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+            Sg[2, 2] = -1
+        R = U @ Sg @ Vt
+        c = np.trace(np.diag(D) @ Sg) / (dx ** 2).sum(1).mean()
+        M = np.eye(4)
+        M[:3, :3] = c * R
+        M[:3, 3] = my - c * R @ mx
+        return M
+
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        x = rng.standard_normal((40, 3)) * 5
+        if trial == 3:
+            x[:, 2] = 0.0  # coplanar points: the third singular value vanishes
+        q = rng.standard_normal(4)
+        R = S3.quat_to_R(q / np.linalg.norm(q))
+        if trial == 4:
+            R = R @ np.diag([1, 1, -1.0])  # a reflection in the data must not leak into R
+        y = 2.5 * (x @ R.T) + np.array([1, 2, 3]) + rng.standard_normal((40, 3)) * 0.01
+        S, rm, mx = L.align_trajectory(x, y)
+        assert np.abs(S - umeyama_np(x, y)).max() < 1e-9
+        assert abs(np.linalg.det(S[:3, :3] / np.cbrt(np.linalg.det(S[:3, :3]))) - 1) < 1e-9
+        al = x @ S[:3, :3].T + S[:3, 3]
+        assert abs(rm - np.sqrt(((y - al) ** 2).sum(1).mean())) < 1e-12
+        assert abs(mx - np.sqrt(((y - al) ** 2).sum(1)).max()) < 1e-12
+    gt = np.loadtxt(os.path.join(K.FIXTURE, "gt_kf.txt"), comments="%")
+    assert gt.shape == (771, 13) and list(gt[:, 0].astype(int)) == K.load_cc()
+    pos = S3.inv(K.build_direct_graph(True)["states"])[:, 4:7]
+    S, rm, mx = L.align_trajectory(pos, gt[:, [4, 8, 12]])
+    assert abs(rm - 130.236) < 1e-2 and abs(mx - 264.069) < 1e-2  # un-optimised VO map vs GT
+    with pytest.raises(L.Sim3OptError):
+        L.align_trajectory(np.zeros((2, 3)), np.zeros((2, 3)))
