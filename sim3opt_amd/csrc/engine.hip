@@ -430,8 +430,7 @@ __global__ __launch_bounds__(WG) void k_spmv(int nb, const int32_t* __restrict__
   const int r = lane % 7;
   const int nchunk = (nb + 3) >> 2;  // 4 block rows per workgroup pass
   int first = blockIdx.x, stride = gridDim.x, last = nchunk;
-  const int ablate = xcd_map >> 4;  // tuning only: 1 = skip the p gather, 2 = skip the block stream
-  if (xcd_map & 1) {
+  if (xcd_map) {
     const int x = blockIdx.x & 7, gx = gridDim.x >> 3;
     first = (int)((long long)nchunk * x / 8) + (blockIdx.x >> 3);
     last = (int)((long long)nchunk * (x + 1) / 8);
@@ -479,15 +478,12 @@ __global__ __launch_bounds__(WG) void k_spmv(int nb, const int32_t* __restrict__
           for (int u = 0; u < CHUNK; ++u) {
             const int ju = j + u < m ? j + u : m - 1;
             const double* vp = vrow + (size_t)49 * ju;
-            v[u] = ablate == 2 ? 1.0 : (NT ? __builtin_nontemporal_load(vp) : *vp);
+            v[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
           }
           // ONE gather instruction fetches the p entries of all CHUNK blocks (lane 7u+c reads
           // p[7*col_u + c]); they reach the (r, c) lanes through the LDS crossbar (ds_bpermute),
           // which is idle here, instead of CHUNK more trips through the address unit
-          if (ablate == 1) {
-#pragma unroll
-            for (int u = 0; u < CHUNK; ++u) xv[u] = 1.0;
-          } else {
+          {
             const int slot = j + gu < m ? j + gu : m - 1;
             const int colu = __shfl(myc, slot);
             const double xg = p[(size_t)7 * colu + gc];
@@ -912,7 +908,7 @@ class Engine {
     }
     if (const char* ev = std::getenv("SIM3OPT_SPMV")) {
       int a = 0, b = 0, c = 0, d = 1;
-      if (std::sscanf(ev, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) { spmv_chunk = a; spmv_nt = b; spmv_xcd = c; spmv_span = d; }  // c: bit0 XCD map, bits 4+ ablation
+      if (std::sscanf(ev, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) { spmv_chunk = a; spmv_nt = b; spmv_xcd = c; spmv_span = d; }
     }
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
@@ -1090,7 +1086,8 @@ class Engine {
     return SIM3OPT_OK;
   }
 
-  // SpMV variant (tuning knob, env SIM3OPT_SPMV="chunk,nt,xcd"; default chosen by measurement)
+  // SpMV variant (tuning knob, env SIM3OPT_SPMV="chunk,nt,xcd,span"; defaults chosen by measurement,
+  // scripts/gpu_spmv_ab.py: span kernel, 8 blocks per step, non-temporal block stream, no XCD remap)
   int spmv_chunk = 8, spmv_nt = 1, spmv_xcd = 0, spmv_span = 1;
 
   int spmv_grid() const {
