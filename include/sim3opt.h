@@ -60,6 +60,9 @@ typedef struct sim3opt_options {
   int32_t pcg_max_iters;    /* 0 = automatic: min(max(7*free vertices, 100), 1000)       */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
+  int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
+                                       -1 = automatic (chain when stored blocks < 4 x block rows)  */
+  int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */
   int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */
   int32_t time_kernels;     /* 0     1: bracket every SpMV / linearise launch with HIP events

@@ -639,19 +639,176 @@ __global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* _
     const bool act = lane < 63 && row < r1;
     const size_t j = (size_t)7 * row + rr;
     const double rv = act ? b[j] : 0.0;
-    double zv = 0.0;
-#pragma unroll
-    for (int cc = 0; cc < 7; ++cc) {
-      const double rc = __shfl(rv, base + cc);
-      if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
-    }
     if (act) {
       x[j] = 0.0;
       r[j] = rv;
-      z[j] = zv;
-      p[j] = zv;
-      rz += rv * zv;
     }
+    if (Minv) {
+      double zv = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 7; ++cc) {
+        const double rc = __shfl(rv, base + cc);
+        if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
+      }
+      if (act) {
+        z[j] = zv;
+        p[j] = zv;
+        rz += rv * zv;
+      }
+    }
+  }
+  if (!Minv) return;
+  const double s = block_sum(rz, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Chain-segment preconditioner (option `preconditioner`): M = the block-tridiagonal part of
+// H + lambda I inside segments of `seg` consecutive block rows (diagonal blocks plus the blocks
+// between rows i and i-1, i.e. the odometry chain of kitti_surf.cpp:649-670), factored exactly:
+//   S_i = D_i + lambda I - G_i L_i^T,  G_i = L_i S_{i-1}^-1,  L_i = H(i, i-1)   (block LDL^T)
+// For chain-like graphs (KITTI-00: 770 rows, 1..118 loops) the preconditioned operator is the
+// identity plus a low-rank term (14 per loop or cut link), so PCG needs tens of iterations where
+// block-Jacobi needs 1e4.  It does not help loop-dominated graphs (measured).
+// ------------------------------------------------------------------------------------------
+// factorisation: one lane per segment (once per LM trial; sequential by nature)
+__global__ __launch_bounds__(64) void k_chain_factor(int r0, int r1, int seg,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const double* __restrict__ vals,
+                                                     const int32_t* __restrict__ sub_first,
+                                                     const int32_t* __restrict__ sub_cnt,
+                                                     double lambda, double* __restrict__ Sinv,
+                                                     double* __restrict__ Gm, DevScalars* sc) {
+  const int sidx = blockIdx.x * 64 + threadIdx.x;
+  const long long start = (long long)r0 + (long long)sidx * seg;
+  if (start >= r1) return;
+  const int row_end = (int)(start + seg < r1 ? start + seg : r1);
+  double P[7][7];  // S_{i-1}^-1
+  bool spd = true;
+  for (int i = (int)start; i < row_end; ++i) {
+    double a[7][7], G[7][7];
+    const double* d = vals + (size_t)49 * rowptr[i];
+    for (int c = 0; c < 7; ++c)
+      for (int r = 0; r < 7; ++r) a[r][c] = d[7 * c + r];
+    for (int k = 0; k < 7; ++k) a[k][k] += lambda;
+    const int nsub = i > start ? sub_cnt[i] : 0;
+    if (nsub > 0) {
+      double Lm[7][7];
+      for (int r = 0; r < 7; ++r)
+        for (int c = 0; c < 7; ++c) Lm[r][c] = 0.0;
+      for (int t = 0; t < nsub; ++t) {  // parallel edges between i and i-1 keep separate blocks
+        const double* l = vals + (size_t)49 * (sub_first[i] + t);
+        for (int c = 0; c < 7; ++c)
+          for (int r = 0; r < 7; ++r) Lm[r][c] += l[7 * c + r];
+      }
+      for (int r = 0; r < 7; ++r)
+        for (int c = 0; c < 7; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < 7; ++k) acc += Lm[r][k] * P[k][c];
+          G[r][c] = acc;
+        }
+      for (int r = 0; r < 7; ++r)
+        for (int c = 0; c < 7; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < 7; ++k) acc += G[r][k] * Lm[c][k];
+          a[r][c] -= acc;
+        }
+    } else {
+      for (int r = 0; r < 7; ++r)
+        for (int c = 0; c < 7; ++c) G[r][c] = 0.0;
+    }
+    for (int k = 0; k < 7; ++k) {  // Gauss-Jordan, positive pivots <=> SPD
+      if (!(a[k][k] > 0.0)) spd = false;
+      const double dd = 1.0 / a[k][k];
+      for (int j = 0; j < 7; ++j)
+        if (j != k) a[k][j] *= dd;
+      for (int r = 0; r < 7; ++r)
+        if (r != k) {
+          const double f = a[r][k];
+          for (int j = 0; j < 7; ++j)
+            if (j != k) a[r][j] -= f * a[k][j];
+          a[r][k] = -f * dd;
+        }
+      a[k][k] = dd;
+    }
+    double* so = Sinv + (size_t)49 * i;
+    double* go = Gm + (size_t)49 * i;
+    for (int r = 0; r < 7; ++r)
+      for (int c = 0; c < 7; ++c) {
+        so[7 * r + c] = a[r][c];
+        go[7 * r + c] = G[r][c];
+        P[r][c] = a[r][c];
+      }
+  }
+  if (!spd) sc->fail = 1;
+}
+
+// application z = M^-1 r and partial r.z: one wavefront per segment, lane = (row rr, column cc)
+// of the 7x7 factor blocks; forward pass y_i = r_i - G_i y_{i-1} (kept in LDS), backward pass
+// z_i = S_i^-1 y_i - G_{i+1}^T z_{i+1}.  Two dependent shuffles per row and direction.
+constexpr int CHAIN_SEG_MAX = 256;
+__global__ __launch_bounds__(WG) void k_chain_apply(int r0, int r1, int seg,
+                                                    const double* __restrict__ Sinv,
+                                                    const double* __restrict__ Gm,
+                                                    const double* __restrict__ r,
+                                                    double* __restrict__ z,
+                                                    double* __restrict__ p_copy,
+                                                    double* __restrict__ partials,
+                                                    const DevScalars* __restrict__ sc) {
+  __shared__ double sh[4];
+  __shared__ double ybuf[4][CHAIN_SEG_MAX * 7];
+  if (sc && sc->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int rr = l49 / 7, cc = l49 % 7;
+  double rz = 0.0;
+  const int nseg = (r1 - r0 + seg - 1) / seg;
+  for (int sidx = blockIdx.x * 4 + wave; sidx < nseg; sidx += gridDim.x * 4) {
+    const int start = r0 + sidx * seg;
+    const int end = start + seg < r1 ? start + seg : r1;
+    double* yb = ybuf[wave];
+    // forward
+    double yprev_cc = 0.0;
+    double g_nx = Gm[(size_t)49 * start + 7 * rr + cc], r_nx = r[(size_t)7 * start + rr];
+    for (int i = start; i < end; ++i) {
+      const double g = g_nx, ri = r_nx;
+      if (i + 1 < end) {  // the next row's factor block and rhs are in flight during this row's shuffles
+        g_nx = Gm[(size_t)49 * (i + 1) + 7 * rr + cc];
+        r_nx = r[(size_t)7 * (i + 1) + rr];
+      }
+      const double prod = g * yprev_cc;
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sum += __shfl(prod, 7 * rr + k);
+      const double yi = ri - sum;  // y_i[rr], identical on the 7 lanes of row rr
+      yprev_cc = __shfl(yi, 7 * cc);                   // y_i[cc] for the next row
+      if (cc == 0 && lane < 49) yb[7 * (i - start) + rr] = yi;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // backward
+    double znext_cc = 0.0;
+    double s_nx = Sinv[(size_t)49 * (end - 1) + 7 * rr + cc], gt_nx = 0.0;
+    for (int i = end - 1; i >= start; --i) {
+      const double yc = yb[7 * (i - start) + cc];
+      const double sv = s_nx, gt = gt_nx;  // S_i^-1 and G_{i+1}^T entries, prefetched
+      if (i > start) {
+        s_nx = Sinv[(size_t)49 * (i - 1) + 7 * rr + cc];
+        gt_nx = Gm[(size_t)49 * i + 7 * cc + rr];
+      }
+      double prod = sv * yc;
+      if (i + 1 < end) prod -= gt * znext_cc;  // G_{i+1}^T
+      double zi = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) zi += __shfl(prod, 7 * rr + k);
+      znext_cc = __shfl(zi, 7 * cc);
+      if (cc == 0 && lane < 49) {
+        z[(size_t)7 * i + rr] = zi;
+        if (p_copy) p_copy[(size_t)7 * i + rr] = zi;
+        rz += r[(size_t)7 * i + rr] * zi;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   const double s = block_sum(rz, sh);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -708,17 +865,20 @@ __global__ __launch_bounds__(WG) void k_pcg_update1(int r0, int r1, int par,
       rv = r[j] - alpha * q[j];
       r[j] = rv;
     }
-    double zv = 0.0;
+    if (Minv) {  // block-Jacobi; the chain preconditioner runs as its own kernel afterwards
+      double zv = 0.0;
 #pragma unroll
-    for (int cc = 0; cc < 7; ++cc) {
-      const double rc = __shfl(rv, base + cc);
-      if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
-    }
-    if (act) {
-      z[j] = zv;
-      rz += rv * zv;
+      for (int cc = 0; cc < 7; ++cc) {
+        const double rc = __shfl(rv, base + cc);
+        if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
+      }
+      if (act) {
+        z[j] = zv;
+        rz += rv * zv;
+      }
     }
   }
+  if (!Minv) return;
   const double s = block_sum(rz, sh);
   if (threadIdx.x == 0) part_rz[blockIdx.x] = s;
 }
@@ -856,6 +1016,11 @@ class Engine {
   double *d_vals = nullptr, *d_scratch = nullptr, *d_b = nullptr, *d_Minv = nullptr;
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_part_a = nullptr, *d_part_b = nullptr;
+  // chain-segment preconditioner (Sinv lives in d_Minv)
+  int32_t *d_sub_first = nullptr, *d_sub_cnt = nullptr;
+  double* d_Gm = nullptr;
+  bool use_chain = false;
+  int chain_seg = 256;
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool linearized = false;
@@ -875,7 +1040,8 @@ class Engine {
   void release() {
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                     d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
-                    d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_part_a, d_part_b, d_sc};
+                    d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_part_a, d_part_b, d_sc,
+                    d_sub_first, d_sub_cnt, d_Gm};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (h_sc) (void)hipHostFree(h_sc);
@@ -970,6 +1136,30 @@ class Engine {
     const size_t ninc = (size_t)s.incptr[nb];
     HIPCHK(hipMalloc((void**)&d_scratch, sizeof(double) * 35 * std::max<size_t>(ninc, 1)));
     HIPCHK(hipMalloc((void**)&d_Minv, sizeof(double) * 49 * (size_t)nb));
+    // preconditioner choice: chain segments for chain-like graphs (few blocks per row)
+    // automatic: chain segments only when almost every edge is a chain link (KITTI with one loop:
+    // 3963 PCG iterations per 30 LM iterations instead of 621642); with many loops the low-rank
+    // argument is gone and the sequential apply costs more than it saves (measured)
+    int64_t chain_links = 0;
+    for (int32_t i = 1; i < nb; ++i)
+      for (int32_t k = s.rowptr[i] + 1; k < s.rowptr[i + 1]; ++k)
+        if (s.colidx[k] == i - 1) { ++chain_links; break; }
+    const int64_t off_chain_edges = (nnzb - nb) / 2 - chain_links;
+    use_chain = opt.preconditioner == 1 ||
+                (opt.preconditioner < 0 && comm.world == 1 && off_chain_edges <= std::max<int64_t>(2, nb / 64));
+    chain_seg = std::max(2, std::min(opt.chain_segment > 0 ? opt.chain_segment : 256, CHAIN_SEG_MAX));
+    if (use_chain) {
+      std::vector<int32_t> sf(nb, -1), scnt(nb, 0);
+      for (int32_t i = 1; i < nb; ++i)
+        for (int32_t k = s.rowptr[i] + 1; k < s.rowptr[i + 1]; ++k)  // sorted by column after the diagonal
+          if (s.colidx[k] == i - 1) {
+            if (sf[i] < 0) sf[i] = k;
+            ++scnt[i];
+          }
+      HIPCHK(upload(d_sub_first, sf));
+      HIPCHK(upload(d_sub_cnt, scnt));
+      HIPCHK(hipMalloc((void**)&d_Gm, sizeof(double) * 49 * (size_t)nb));
+    }
     double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q};
     for (double** v : vecs) {
       HIPCHK(hipMalloc((void**)v, sizeof(double) * (size_t)n));
@@ -1141,18 +1331,32 @@ class Engine {
     const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
     int rc = SIM3OPT_OK;
     HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, r0, r1, d_rowptr, d_vals, lambda,
-                       d_Minv, d_sc);
-    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, d_Minv, d_x, d_r,
-                       d_z, d_p, d_part_b);
+    const int nseg = (nloc + chain_seg - 1) / chain_seg;
+    const int gc = grid_for(nseg, 4);             // chain apply: one wavefront per segment
+    const int gz = use_chain ? gc : gv;           // number of r.z partials
+    const double* Minv_arg = use_chain ? nullptr : d_Minv;
+    if (use_chain) {
+      hipLaunchKernelGGL(k_chain_factor, dim3(std::max(1, (nseg + 63) / 64)), dim3(64), 0, stream,
+                         r0, r1, chain_seg, d_rowptr, d_vals, d_sub_first, d_sub_cnt, lambda,
+                         d_Minv, d_Gm, d_sc);
+      hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x,
+                         d_r, d_z, d_p, d_part_b);
+      hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
+                         d_Gm, d_r, d_z, d_p, d_part_b, (const DevScalars*)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, r0, r1, d_rowptr, d_vals, lambda,
+                         d_Minv, d_sc);
+      hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x,
+                         d_r, d_z, d_p, d_part_b);
+    }
     if (multi) {
-      hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gv, &d_sc->tmp_rz);
+      hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gz, &d_sc->tmp_rz);
       rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
       if (rc) return rc;
       rc = comm.allgatherv(d_p, offs, stream, err);
       if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(WG), 0, stream, d_part_b, gv, d_sc, max_it,
+    hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(WG), 0, stream, d_part_b, gz, d_sc, max_it,
                        tol2, rz_s);
     HIPCHK(hipGetLastError());
     const int chunk = std::max(1, opt.pcg_check_every);
@@ -1164,7 +1368,7 @@ class Engine {
         rc = pool_drain(err);
         if (rc) return rc;
       }
-      if (h_sc->done || it >= max_it) break;
+      if (h_sc->done || h_sc->fail || it >= max_it) break;
       const int todo = std::min(chunk, max_it - it);
       for (int c = 0; c < todo; ++c) {
         rc = spmv_launch(lambda, true, err);
@@ -1176,15 +1380,19 @@ class Engine {
           if (rc) return rc;
         }
         hipLaunchKernelGGL(k_pcg_update1, dim3(gv), dim3(WG), 0, stream, r0, r1, par, pq_s,
-                           d_part_a, gs, d_Minv, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
+                           d_part_a, gs, Minv_arg, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
+        if (use_chain)
+          hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
+                             d_Minv, d_Gm, d_r, d_z, (double*)nullptr, d_part_b,
+                             (const DevScalars*)d_sc);
         if (multi) {
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gv,
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gz,
                              &d_sc->tmp_rz);
           rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
           if (rc) return rc;
         }
         hipLaunchKernelGGL(k_pcg_update2, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, par, rz_s,
-                           d_part_b, gv, d_z, d_p, d_sc);
+                           d_part_b, gz, d_z, d_p, d_sc);
         if (multi) {
           rc = comm.allgatherv(d_p, offs, stream, err);
           if (rc) return rc;
