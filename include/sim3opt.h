@@ -57,6 +57,9 @@ typedef struct sim3opt_options {
   int32_t small_rot_half;   /* 0     R = I+W+W^2 (sim3_rv.h:151); 1: I+W+W^2/2           */
   int32_t fix_small_angle_b;/* 0     B coefficient as written in sim3_rv.h:166/:290 (reference
                                         behaviour); 1: exact small-theta limit               */
+  int32_t dof_mask;         /* 127   bit d set = tangent component d ([w0 w1 w2 u0 u1 u2 s]) is
+                                        optimised; cleared bits freeze it (0x78 = rotations frozen:
+                                        the scale+translation stage, kitti_surf.cpp:1020-1024)    */
   int32_t pcg_max_iters;    /* 0 = automatic: min(max(7*free vertices, 100), 1000)       */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
@@ -202,6 +205,15 @@ int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one
 /* Writes "kfid s tx ty tz qx qy qz qw" rows (S_wi of each estimate)  kitti_surf.cpp:678-701;
  * precision: 17 significant digits (the reference prints 6). image_ids may be NULL. */
 int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids);
+
+/* ---- stepwise optimisation, stage 1 (host C++) ----
+ * "scale_dlt" of testStepwiseSim3Optimization                        kitti_surf.cpp:887-933
+ * Null vector of the edge equations s_C x[v0] - x[v1] = 0 (the reference: last column of V of
+ * Eigen::JacobiSVD), divided by its first entry, written into the scale of every vertex estimate.
+ * Needs dense vertex ids 0..n-1 and n <= 4096.  sigma_ratio (optional) receives an estimate of
+ * sigma_min / sigma_max (the reference warns below 5e-4).  Stage 2 / 3 are optimize() runs with
+ * dof_mask = 0x78 (rotations frozen) / 127, each warm-started from the previous stage. */
+int sim3opt_stepwise_scale_init(sim3opt_graph* g, double* sigma_ratio);
 
 /* ---- evaluation harness (host C++) ----
  * estimateSimilarityTransform = Eigen::umeyama(query, train, true)   kitti_surf.cpp:1091-1161

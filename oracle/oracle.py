@@ -25,6 +25,7 @@ class Options(C.Structure):
         ("exp_eps", C.c_double),
         ("small_rot_half", C.c_int),
         ("fix_small_angle_b", C.c_int),
+        ("dof_mask", C.c_int),
         ("threads", C.c_int),
     ]
 

@@ -40,6 +40,7 @@ void or_options_default(or_options *o) {
   o->exp_eps = 1e-5;
   o->small_rot_half = 0;
   o->fix_small_angle_b = 0;
+  o->dof_mask = 127;
   o->threads = 1;
 }
 
@@ -283,7 +284,7 @@ static void numeric_block(const or_sim3 *C, const or_sim3 *S0, const or_sim3 *S1
     or_sim3_mul(&P, which == 0 ? S0 : S1, &Sp);
     or_edge_error(C, which == 0 ? &Sp : S0, which == 0 ? S1 : &Sp, o, em);
     add[d] = 0.0;
-    for (int r = 0; r < 7; ++r) J[7 * d + r] = scalar * (ep[r] - em[r]);
+    for (int r = 0; r < 7; ++r) J[7 * d + r] = ((o->dof_mask >> d) & 1) ? scalar * (ep[r] - em[r]) : 0.0;
   }
 }
 

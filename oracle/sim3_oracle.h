@@ -44,6 +44,8 @@ typedef struct {
   int    small_rot_half;    /* 0: R=I+W+W^2 (sim3_rv.h:151); 1: I+W+W^2/2     */
   int    fix_small_angle_b; /* 0: B as written (sim3_rv.h:166, :290); 1: exact
                                small-theta limit ((s2/2-s+1)e^s-1)/s^3          */
+  int    dof_mask;          /* 127    bit d set = tangent component d is free; cleared bits
+                               zero that Jacobian column (frozen rotation: 0x78)   */
   int    threads;           /* 1      OpenMP threads for per-edge loops       */
 } or_options;
 

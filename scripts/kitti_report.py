@@ -37,6 +37,36 @@ for name, one in (("one_loop", True), ("all_118_loops", False)):
         rec["rmse_gpu_vs_oracle_m"] = synth.rmse(G.get_vertices(), OG.states)
         out[f"{name}/fix_small_angle_b={fixb}"] = rec
         print(name, fixb, json.dumps(rec), flush=True)
+# config 5 (a): the reference's stepwise staging (kitti_surf.cpp:887-1047), 100 + 100 iterations
+for fixb in (0, 1):
+    g = K.build_direct_graph(False)
+    G = L.Graph(fix_small_angle_b=fixb, pcg_rel_tol=1e-10, pcg_max_iters=20000)
+    G.add_vertices(g["states"], g["fixed"]); G.add_edges(g["v0"], g["v1"], g["meas"])
+    t0 = time.perf_counter(); G.stepwise_scale_init(); t1 = time.perf_counter()
+    r1 = L.align_trajectory(synth.positions(G.get_vertices()), gt)[1]
+    G.set_options(dof_mask=0x78); G.initialize()
+    n2 = 0
+    while n2 < 100:
+        k = G._L.sim3opt_optimize(G._g, 100 - n2)
+        if k <= 0: break
+        n2 += k
+        if G.stats()[-1].trials >= 10 or G.stats()[-1].rho == 0: break
+    t2 = time.perf_counter(); chi2_2 = G.stats()[-1].chi2_after
+    r2 = L.align_trajectory(synth.positions(G.get_vertices()), gt)[1]
+    G.set_options(dof_mask=127)
+    n3 = 0
+    while n3 < 100:
+        k = G._L.sim3opt_optimize(G._g, 100 - n3)
+        if k <= 0: break
+        n3 += k
+        if G.stats()[-1].trials >= 10 or G.stats()[-1].rho == 0: break
+    t3 = time.perf_counter()
+    out[f"stepwise_all_loops/fix_small_angle_b={fixb}"] = dict(
+        scale_dlt_s=t1 - t0, rmse_after_scales_m=r1, scale_trans_iters=n2, scale_trans_s=t2 - t1,
+        scale_trans_chi2=chi2_2, rmse_after_scale_trans_m=r2, sim3_iters=n3, sim3_s=t3 - t2,
+        sim3_chi2=G.stats()[-1].chi2_after,
+        rmse_vs_gt_m=L.align_trajectory(synth.positions(G.get_vertices()), gt)[1])
+    print("stepwise", fixb, json.dumps(out[f"stepwise_all_loops/fix_small_angle_b={fixb}"]), flush=True)
 # config 5 (b): incremental loop closures, warm-started LM (<= 20 iterations) per closure
 full = K.build_direct_graph(False); nl = 118
 G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, pcg_max_iters=20000)

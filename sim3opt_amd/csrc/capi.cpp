@@ -126,6 +126,7 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->exp_eps = 1e-5;
   o->small_rot_half = 0;
   o->fix_small_angle_b = 0;
+  o->dof_mask = 127;
   o->pcg_max_iters = 0;
   o->pcg_rel_tol = 1e-10;
   o->pcg_check_every = 16;

@@ -207,6 +207,7 @@ struct LinArgs {
   double* scratch;
   double delta;
   sim3::Opts opts;
+  int32_t dof_mask;  // cleared bit d: Jacobian column d of both endpoints is zero (frozen DoF)
 };
 
 struct GramTables {
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const double other = __shfl_down(e[r], 1);  // lane l+1 holds the -delta evaluation
-    if (valid && l < 28 && !(l & 1)) s_J[es][l >> 1][r] = scalar * (e[r] - other);
+    if (valid && l < 28 && !(l & 1))
+      s_J[es][l >> 1][r] = ((A.dof_mask >> ((l % 14) >> 1)) & 1) ? scalar * (e[r] - other) : 0.0;
     if (valid && l == 28) s_J[es][14][r] = e[r];
   }
   __syncthreads();
@@ -1252,7 +1254,8 @@ class Engine {
     }
     HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
     LinArgs A{n_active, d_active, d_ev0, d_ev1, d_meas, d_info, d_kdelta, d_states,
-              d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts()};
+              d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts(),
+              opt.dof_mask};
     const int g = (n_active + EPB - 1) / EPB;
     if (g > 0) {
       if (has_info && has_kernel)

@@ -29,6 +29,7 @@ class Options(C.Structure):
         ("exp_eps", C.c_double),
         ("small_rot_half", C.c_int32),
         ("fix_small_angle_b", C.c_int32),
+        ("dof_mask", C.c_int32),
         ("pcg_max_iters", C.c_int32),
         ("pcg_rel_tol", C.c_double),
         ("pcg_check_every", C.c_int32),
@@ -110,6 +111,7 @@ SYMBOLS = {
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
+    "sim3opt_stepwise_scale_init": (C.c_int, [_vp, _dp]),
     "sim3opt_align_trajectory": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _dp]),
 }
 
@@ -395,6 +397,12 @@ class Graph:
     def load_kitti_direct(self, directory, use_one_constraint=True):
         self._chk(self._L.sim3opt_load_kitti_direct(self._g, os.fsencode(directory),
                                                     int(bool(use_one_constraint))))
+
+    def stepwise_scale_init(self):
+        """Stage 1 of the stepwise pipeline; returns the sigma_min/sigma_max estimate."""
+        r = C.c_double()
+        self._chk(self._L.sim3opt_stepwise_scale_init(self._g, C.byref(r)))
+        return r.value
 
     def write_poses(self, path, image_ids=None):
         ids = None if image_ids is None else _i32(image_ids)

@@ -342,3 +342,16 @@ def test_openmp_variant_is_identical():
     a = G1.optimize(3, O.default_options(threads=1))
     b = G8.optimize(3, O.default_options(threads=4))
     assert np.array_equal(G1.states, G8.states)
+
+
+def test_dof_mask_freezes_tangent_components():
+    """Stage 2 of the stepwise pipeline: cleared dof_mask bits zero the Jacobian columns."""
+    g, G = small_graph(4)
+    o = O.default_options(dof_mask=0x78, fix_small_angle_b=1)
+    A, B = G.jacobians(o)
+    assert np.all(A[:, :, :3] == 0) and np.all(B[:, :, :3] == 0)
+    assert np.abs(A[:, :, 3:]).max() > 0
+    q0 = G.states[:, :4].copy()
+    it, tr = G.optimize(4, o)
+    assert it == 4 and np.array_equal(G.states[:, :4], q0)
+    assert tr[-1].chi2_after < tr[0].chi2_before
