@@ -64,7 +64,8 @@ typedef struct sim3opt_options {
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
-                                       -1 = automatic (chain when stored blocks < 4 x block rows)  */
+                                       -1 = automatic: chain for nearly pure chains (off-chain edges
+                                       <= rows/64) in the well-posed arithmetic, else block-Jacobi  */
   int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */
   int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */

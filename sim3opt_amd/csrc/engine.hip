@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -48,7 +49,8 @@ constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of
 
 // Scalars that live in HBM so the PCG loop needs no host round trip per iteration.
 struct DevScalars {
-  double rz[2];    // r.z of the current / next PCG iteration (ping-pong by parity)
+  double rz[2];    // gamma = r.z of the previous PCG iteration (ping-pong by parity)
+  double alpha[2]; // step length of the previous PCG iteration (ping-pong by parity)
   double rz0;      // r.z at PCG start
   double chi2;     // sum of (robustified) edge chi2
   double scale;    // x.(lambda x + b)
@@ -56,10 +58,12 @@ struct DevScalars {
   int32_t iter;      // PCG iterations executed
   int32_t max_iter;  // PCG iteration cap
   int32_t done;      // PCG finished (converged, cap reached or breakdown)
+  int32_t stop;      // set by the last allowed update; turned into `done` by the next launch
   int32_t fail;      // PCG breakdown (p.q <= 0 or non-finite) or non-SPD diagonal block
   double tol2;       // squared relative tolerance on ||r||_Minv
-  double tmp_pq;     // multi-GPU: p.q summed over ranks (all-reduced in place)
-  double tmp_rz;     // multi-GPU: r.z summed over ranks
+  double tmp_pq;     // multi-GPU: w.z summed over ranks  } adjacent: ONE 2-double all-reduce
+  double tmp_rz;     // multi-GPU: r.z summed over ranks  } per PCG iteration
+  double gam_last;   // r.z seen by the last executed step (reported relative residual)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -406,117 +410,19 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 // PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
 // row's 7 entries sit in one wavefront (z = Minv r by shuffles) and addresses stay contiguous.
 // ------------------------------------------------------------------------------------------
-// q = (H + lambda I) p, partial p.q per workgroup.  One wavefront per block row, lane = one of
-// the 49 entries of the current 7x7 block; a row's blocks are one contiguous HBM stream.
-//   * CHUNK blocks are fetched back to back before any use (CHUNK x 392 B in flight per
-//     wavefront): the kernel is latency-bound otherwise;
-//   * column indices are wave-uniform (scalar loads), so the gathers of p do not wait on a
-//     vector load;
-//   * NT: the once-read block stream bypasses the cache policy so that p (7*nb doubles,
-//     re-read ~deg times) stays resident in the XCD's L2;
-//   * XCD: workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x the x-th contiguous
-//     eighth of the rows keeps each L2's share of p to the columns near that eighth.  Only speed
-//     depends on the placement, never the result.
-template <int CHUNK, bool NT>
-__global__ __launch_bounds__(WG) void k_spmv(int nb, const int32_t* __restrict__ rowptr,
-                                             const int32_t* __restrict__ colidx,
-                                             const double* __restrict__ vals,
-                                             const double* __restrict__ p,
-                                             double* __restrict__ q, double lambda,
-                                             double* __restrict__ partials,
-                                             const DevScalars* __restrict__ sc, int xcd_map) {
-  __shared__ double sh[4];
-  if (sc && sc->done) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane % 7;
-  const int nchunk = (nb + 3) >> 2;  // 4 block rows per workgroup pass
-  int first = blockIdx.x, stride = gridDim.x, last = nchunk;
-  if (xcd_map) {
-    const int x = blockIdx.x & 7, gx = gridDim.x >> 3;
-    first = (int)((long long)nchunk * x / 8) + (blockIdx.x >> 3);
-    last = (int)((long long)nchunk * (x + 1) / 8);
-    stride = gx;
-  }
-  // lanes 49..63 mirror lanes 0..14: every lane issues a valid, coalesced load (no exec masking,
-  // no branches around the loads); their products are never read by the reduction below.
-  const int l49 = lane < 49 ? lane : lane - 49;
-  const int c49 = l49 / 7;
-  const int gu = lane / 7 < CHUNK ? lane / 7 : CHUNK - 1, gc = lane % 7;  // gather slot of this lane
-  double pq = 0.0;
-  // Row metadata (row pointers + the row's column indices) is fetched one row AHEAD, so a row
-  // costs one dependent memory round trip per CHUNK blocks instead of three extra ones.
-  int nk0 = 0, nnblk = 0, nmyc = 0;
-  if (first < last && first * 4 + wave < nb) {
-    const int row = first * 4 + wave;
-    nk0 = rowptr[row];
-    nnblk = rowptr[row + 1] - nk0;
-    nmyc = lane < nnblk ? colidx[nk0 + lane] : 0;
-  }
-  for (int ch = first; ch < last; ch += stride) {
-    const int row = ch * 4 + wave;
-    if (row < nb) {
-      const int k0 = nk0, nblk = nnblk;
-      const int myc0 = nmyc;
-      {
-        const int nrow = (ch + stride) * 4 + wave;
-        if (ch + stride < last && nrow < nb) {
-          nk0 = rowptr[nrow];
-          nnblk = rowptr[nrow + 1] - nk0;
-          nmyc = lane < nnblk ? colidx[nk0 + lane] : 0;
-        }
-      }
-      double acc = 0.0;
-      for (int base = 0; base < nblk; base += 64) {
-        // the row's column indices: ONE coalesced vector load (prefetched for the first 64)
-        const int myc = base == 0 ? myc0 : ((base + lane < nblk) ? colidx[k0 + base + lane] : 0);
-        const int m = nblk - base < 64 ? nblk - base : 64;
-        const double* vrow = vals + (size_t)49 * (k0 + base) + l49;
-        // CHUNK blocks per step, all loads issued before the first use; the last step re-reads
-        // the row's final block for its missing slots (cache hit) and weights them with zero
-        for (int j = 0; j < m; j += CHUNK) {
-          double v[CHUNK], xv[CHUNK];
-#pragma unroll
-          for (int u = 0; u < CHUNK; ++u) {
-            const int ju = j + u < m ? j + u : m - 1;
-            const double* vp = vrow + (size_t)49 * ju;
-            v[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
-          }
-          // ONE gather instruction fetches the p entries of all CHUNK blocks (lane 7u+c reads
-          // p[7*col_u + c]); they reach the (r, c) lanes through the LDS crossbar (ds_bpermute),
-          // which is idle here, instead of CHUNK more trips through the address unit
-          {
-            const int slot = j + gu < m ? j + gu : m - 1;
-            const int colu = __shfl(myc, slot);
-            const double xg = p[(size_t)7 * colu + gc];
-#pragma unroll
-            for (int u = 0; u < CHUNK; ++u) xv[u] = __shfl(xg, 7 * u + c49);
-          }
-#pragma unroll
-          for (int u = 0; u < CHUNK; ++u) acc += (j + u < m ? v[u] : 0.0) * xv[u];
-        }
-      }
-      double y = acc;
-#pragma unroll
-      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-      if (lane < 7) {
-        const double pi = p[(size_t)7 * row + lane];
-        y += lambda * pi;
-        q[(size_t)7 * row + lane] = y;
-        pq += pi * y;
-      }
-    }
-  }
-  const double s = block_sum(pq, sh);
-  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
-}
-
-// Span variant of the SpMV: each wavefront owns a CONTIGUOUS span of block rows (host table
-// `wrow`, balanced by block count), so its blocks and column indices are one contiguous stream
-// that is software-pipelined across row boundaries: the loads of chunk k+1 (CH blocks, one shared
-// gather of p) are in flight while chunk k is consumed; a row ends with a wave-uniform branch
-// (reduce 7 columns, add lambda p, store q, accumulate p.q).  Same arithmetic order per row as
-// k_spmv, so q is bit-identical; only the grouping of the p.q partials differs.
+// q = (H + lambda I) p with the partial dot products p.q and (optionally) rvec.p per workgroup --
+// the block-CSR SpMV of the PCG (LinearSolverEigen's role, kitti_surf.cpp:553-554).
+// One wavefront owns a CONTIGUOUS span of block rows (host table `wrow`, balanced by block count);
+// lane = one of the 49 entries of the current 7x7 block, so its blocks and column indices are one
+// contiguous HBM stream, software-pipelined across row boundaries:
+//   * the loads of chunk k+1 (CH blocks of 392 B + ONE shared gather of p: lane 7u+c reads
+//     p[7 col_u + c]) are in flight while chunk k is consumed; the p entries reach the (r, c) lanes
+//     through the LDS crossbar (ds_bpermute), which is otherwise idle -- with one gather per block
+//     the address unit, not HBM, was the co-bottleneck (measured);
+//   * lanes 49..63 mirror lanes 0..14: every lane issues a valid coalesced load, no exec masking;
+//   * column indices / row ends: one coalesced vector load per 64, then v_readlane / ds_bpermute;
+//   * NT: the once-read block stream bypasses the cache policy so p stays in L2 / Infinity Cache;
+//   * a row ends with a wave-uniform branch (reduce 7 columns, add lambda p, store q, dots).
 template <int CH, bool NT>
 __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
@@ -525,9 +431,15 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
                                                   const double* __restrict__ p,
                                                   double* __restrict__ q, double lambda,
                                                   double* __restrict__ partials,
-                                                  const DevScalars* __restrict__ sc) {
+                                                  const double* __restrict__ rvec,
+                                                  double* __restrict__ partials_r,
+                                                  DevScalars* __restrict__ sc) {
   __shared__ double sh[4];
-  if (sc && sc->done) return;
+  if (sc) {
+    if (sc->done) return;
+    // the previous update was the last allowed one: later launches become no-ops
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sc->stop) sc->done = 1;
+  }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int r = lane % 7;
@@ -535,7 +447,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   const int c49 = l49 / 7;
   const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
   const int rA = wrow[w], rB = wrow[w + 1];
-  double pq = 0.0;
+  double pq = 0.0, pr = 0.0;
   if (rA < rB) {
     const int kbeg = rowptr[rA], kend = rowptr[rB];
     // row ends of this span, 64 at a time, one per lane
@@ -593,6 +505,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
               y += lambda * pi;
               q[(size_t)7 * row + lane] = y;
               pq += pi * y;
+              if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
             }
             acc = 0.0;
             ++row;
@@ -618,24 +531,27 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
         y += lambda * pi;
         q[(size_t)7 * row + lane] = y;
         pq += pi * y;
+        if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
       }
     }
   }
   const double s = block_sum(pq, sh);
   if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
+  if (rvec) {
+    const double t = block_sum(pr, sh);
+    if (threadIdx.x == 0) partials_r[blockIdx.x] = t;
+  }
 }
 
-// x = 0, r = b, z = Minv b, p = z, partial r.z
+// x = 0, r = b, z = Minv b (block-Jacobi; the chain preconditioner runs separately), p = s = 0
 __global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* __restrict__ b,
                                                  const double* __restrict__ Minv,
                                                  double* __restrict__ x, double* __restrict__ r,
                                                  double* __restrict__ z, double* __restrict__ p,
-                                                 double* __restrict__ partials) {
-  __shared__ double sh[4];
+                                                 double* __restrict__ sv) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  double rz = 0.0;
   for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
     const int row = row0 + sub;
     const bool act = lane < 63 && row < r1;
@@ -644,6 +560,8 @@ __global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* _
     if (act) {
       x[j] = 0.0;
       r[j] = rv;
+      p[j] = 0.0;
+      sv[j] = 0.0;
     }
     if (Minv) {
       double zv = 0.0;
@@ -652,16 +570,9 @@ __global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* _
         const double rc = __shfl(rv, base + cc);
         if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
       }
-      if (act) {
-        z[j] = zv;
-        p[j] = zv;
-        rz += rv * zv;
-      }
+      if (act) z[j] = zv;
     }
   }
-  if (!Minv) return;
-  const double s = block_sum(rz, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -754,17 +665,13 @@ __global__ __launch_bounds__(WG) void k_chain_apply(int r0, int r1, int seg,
                                                     const double* __restrict__ Gm,
                                                     const double* __restrict__ r,
                                                     double* __restrict__ z,
-                                                    double* __restrict__ p_copy,
-                                                    double* __restrict__ partials,
                                                     const DevScalars* __restrict__ sc) {
-  __shared__ double sh[4];
   __shared__ double ybuf[4][CHAIN_SEG_MAX * 7];
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int l49 = lane < 49 ? lane : lane - 49;
   const int rr = l49 / 7, cc = l49 % 7;
-  double rz = 0.0;
   const int nseg = (r1 - r0 + seg - 1) / seg;
   for (int sidx = blockIdx.x * 4 + wave; sidx < nseg; sidx += gridDim.x * 4) {
     const int start = r0 + sidx * seg;
@@ -804,110 +711,90 @@ __global__ __launch_bounds__(WG) void k_chain_apply(int r0, int r1, int seg,
 #pragma unroll
       for (int k = 0; k < 7; ++k) zi += __shfl(prod, 7 * rr + k);
       znext_cc = __shfl(zi, 7 * cc);
-      if (cc == 0 && lane < 49) {
-        z[(size_t)7 * i + rr] = zi;
-        if (p_copy) p_copy[(size_t)7 * i + rr] = zi;
-        rz += r[(size_t)7 * i + rr] * zi;
-      }
+      if (cc == 0 && lane < 49) z[(size_t)7 * i + rr] = zi;
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const double s = block_sum(rz, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void k_pcg_init_final(const double* __restrict__ partials, int n, DevScalars* sc,
-                                 int max_iter, double tol2, const double* __restrict__ scalar) {
-  __shared__ double sh[4];
-  const double s = scalar ? *scalar : sum_partials(partials, n, sh);
-  if (threadIdx.x == 0) {
-    sc->rz[0] = s;
-    sc->rz[1] = 0.0;
-    sc->rz0 = s;
-    sc->iter = 0;
-    sc->max_iter = max_iter;
-    sc->tol2 = tol2;
-    sc->done = (s == 0.0 || !(s == s)) ? 1 : 0;
-    if (!(s == s) || s < 0.0) sc->fail = 1;
-  }
-}
-
-// alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z
-__global__ __launch_bounds__(WG) void k_pcg_update1(int r0, int r1, int par,
-                                                    const double* __restrict__ pq_scalar,
-                                                    const double* __restrict__ part_pq, int npart,
-                                                    const double* __restrict__ Minv,
-                                                    const double* __restrict__ p,
-                                                    const double* __restrict__ q,
-                                                    double* __restrict__ x, double* __restrict__ r,
-                                                    double* __restrict__ z,
-                                                    double* __restrict__ part_rz, DevScalars* sc) {
+// One PCG iteration in the single-reduction form (Chronopoulos & Gear): the SpMV launch before
+// this one produced w = (H + lambda I) z and the partials of delta = w.z and gamma = r.z, so the
+// iteration has ONE reduction point (one 2-double all-reduce on multi-GPU) and two launches:
+//   beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)
+//   p = z + beta p,  s = w + beta s (= A p),  x += alpha p,  r -= alpha s,  z = Minv r
+// Workgroup 0 commits gamma / alpha for the next launch (ping-pong by parity, so no workgroup
+// reads what another one writes in the same launch) and the stopping decision.
+__global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it,
+                                                 const double* __restrict__ scal,
+                                                 const double* __restrict__ part_d,
+                                                 const double* __restrict__ part_g, int npart,
+                                                 const double* __restrict__ Minv,
+                                                 double* __restrict__ z,
+                                                 const double* __restrict__ w,
+                                                 double* __restrict__ p, double* __restrict__ sv,
+                                                 double* __restrict__ x, double* __restrict__ r,
+                                                 DevScalars* sc) {
   __shared__ double sh[4];
   if (sc->done) return;
-  const double pq = pq_scalar ? *pq_scalar : sum_partials(part_pq, npart, sh);
-  if (!(pq > 0.0) || !(pq < DBL_MAX)) {  // breakdown: not SPD or non-finite
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+  const double delta = scal ? scal[0] : sum_partials(part_d, npart, sh);
+  const double gamma = scal ? scal[1] : sum_partials(part_g, npart, sh);
+  const bool first = it == 0;
+  const double gamma0 = first ? gamma : sc->rz0;
+  const bool commit = blockIdx.x == 0 && threadIdx.x == 0;
+  if (!(gamma == gamma) || gamma < 0.0 || gamma <= sc->tol2 * gamma0 || (first && gamma == 0.0)) {
+    if (commit) {  // converged (x is final) or broken down; every workgroup sees the same gamma
+      if (!(gamma == gamma) || gamma < 0.0) sc->fail = 1;
+      if (first) sc->rz0 = gamma;
+      sc->rz[par ^ 1] = gamma;
+      sc->gam_last = gamma;
+      sc->done = 1;
+    }
+    return;
+  }
+  const double beta = first ? 0.0 : gamma / sc->rz[par];
+  const double denom = first ? delta : delta - beta * gamma / sc->alpha[par];
+  if (!(denom > 0.0) || !(denom < DBL_MAX)) {  // not positive definite (g2o: Cholesky fails)
+    if (commit) {
       sc->fail = 1;
       sc->done = 1;
     }
     return;
   }
-  const double alpha = sc->rz[par] / pq;
+  const double alpha = gamma / denom;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  double rz = 0.0;
   for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
     const int row = row0 + sub;
     const bool act = lane < 63 && row < r1;
     const size_t j = (size_t)7 * row + rr;
     double rv = 0.0;
     if (act) {
-      x[j] += alpha * p[j];
-      rv = r[j] - alpha * q[j];
+      const double pn = z[j] + beta * p[j];
+      const double sn = w[j] + beta * sv[j];
+      p[j] = pn;
+      sv[j] = sn;
+      x[j] += alpha * pn;
+      rv = r[j] - alpha * sn;
       r[j] = rv;
     }
-    if (Minv) {  // block-Jacobi; the chain preconditioner runs as its own kernel afterwards
+    if (Minv) {
       double zv = 0.0;
 #pragma unroll
       for (int cc = 0; cc < 7; ++cc) {
         const double rc = __shfl(rv, base + cc);
         if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
       }
-      if (act) {
-        z[j] = zv;
-        rz += rv * zv;
-      }
+      if (act) z[j] = zv;
     }
   }
-  if (!Minv) return;
-  const double s = block_sum(rz, sh);
-  if (threadIdx.x == 0) part_rz[blockIdx.x] = s;
-}
-
-// beta = rz_new / rz ; p = z + beta p ; workgroup 0 commits rz_new, the iteration count and the
-// stopping decision for the NEXT launches.
-__global__ __launch_bounds__(WG) void k_pcg_update2(int j0, int j1, int par,
-                                                    const double* __restrict__ rz_scalar,
-                                                    const double* __restrict__ part_rz, int npart,
-                                                    const double* __restrict__ z,
-                                                    double* __restrict__ p, DevScalars* sc) {
-  __shared__ double sh[4];
-  if (sc->done) return;
-  const double rz_new = rz_scalar ? *rz_scalar : sum_partials(part_rz, npart, sh);
-  const double beta = rz_new / sc->rz[par];
-  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
-    p[j] = z[j] + beta * p[j];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    sc->rz[par ^ 1] = rz_new;
-    const int it = sc->iter + 1;
-    sc->iter = it;
-    if (!(rz_new == rz_new)) {
-      sc->fail = 1;
-      sc->done = 1;
-    } else if (rz_new <= sc->tol2 * sc->rz0 || it >= sc->max_iter) {
-      sc->done = 1;
-    }
+  if (commit) {
+    if (first) sc->rz0 = gamma;
+    sc->rz[par ^ 1] = gamma;
+    sc->gam_last = gamma;
+    sc->alpha[par ^ 1] = alpha;
+    sc->iter = it + 1;
+    if (it + 1 >= sc->max_iter) sc->stop = 1;
   }
 }
 
@@ -1016,7 +903,7 @@ class Engine {
   int span_grid = 0;  // workgroups of the span SpMV
   int32_t *d_slot01 = nullptr, *d_slot10 = nullptr, *d_inc0 = nullptr, *d_inc1 = nullptr;
   double *d_vals = nullptr, *d_scratch = nullptr, *d_b = nullptr, *d_Minv = nullptr;
-  double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
+  double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_s = nullptr;
   double *d_part_a = nullptr, *d_part_b = nullptr;
   // chain-segment preconditioner (Sinv lives in d_Minv)
   int32_t *d_sub_first = nullptr, *d_sub_cnt = nullptr;
@@ -1042,7 +929,7 @@ class Engine {
   void release() {
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                     d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
-                    d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_part_a, d_part_b, d_sc,
+                    d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
                     d_sub_first, d_sub_cnt, d_Gm};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -1075,8 +962,8 @@ class Engine {
       HIPCHK(hipSetDevice(opt.device));
     }
     if (const char* ev = std::getenv("SIM3OPT_SPMV")) {
-      int a = 0, b = 0, c = 0, d = 1;
-      if (std::sscanf(ev, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) { spmv_chunk = a; spmv_nt = b; spmv_xcd = c; spmv_span = d; }
+      int a = 0, b = 0;
+      if (std::sscanf(ev, "%d,%d", &a, &b) == 2) { spmv_chunk = a; spmv_nt = b; }
     }
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
@@ -1147,8 +1034,12 @@ class Engine {
       for (int32_t k = s.rowptr[i] + 1; k < s.rowptr[i + 1]; ++k)
         if (s.colidx[k] == i - 1) { ++chain_links; break; }
     const int64_t off_chain_edges = (nnzb - nb) / 2 - chain_links;
+    // (only in the well-posed arithmetic: as written, cond(H + lambda I) reaches 1e12 on KITTI, the
+    // recursive residual of a strongly preconditioned CG drifts from the true one, and LM leaves
+    // the exact-Cholesky trajectory at its second iteration -- measured)
     use_chain = opt.preconditioner == 1 ||
-                (opt.preconditioner < 0 && comm.world == 1 && off_chain_edges <= std::max<int64_t>(2, nb / 64));
+                (opt.preconditioner < 0 && comm.world == 1 && opt.fix_small_angle_b != 0 &&
+                 off_chain_edges <= std::max<int64_t>(2, nb / 64));
     chain_seg = std::max(2, std::min(opt.chain_segment > 0 ? opt.chain_segment : 256, CHAIN_SEG_MAX));
     if (use_chain) {
       std::vector<int32_t> sf(nb, -1), scnt(nb, 0);
@@ -1162,7 +1053,7 @@ class Engine {
       HIPCHK(upload(d_sub_cnt, scnt));
       HIPCHK(hipMalloc((void**)&d_Gm, sizeof(double) * 49 * (size_t)nb));
     }
-    double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q};
+    double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q, &d_s};
     for (double** v : vecs) {
       HIPCHK(hipMalloc((void**)v, sizeof(double) * (size_t)n));
       HIPCHK(hipMemset(*v, 0, sizeof(double) * (size_t)n));
@@ -1279,89 +1170,98 @@ class Engine {
     return SIM3OPT_OK;
   }
 
-  // SpMV variant (tuning knob, env SIM3OPT_SPMV="chunk,nt,xcd,span"; defaults chosen by measurement,
-  // scripts/gpu_spmv_ab.py: span kernel, 8 blocks per step, non-temporal block stream, no XCD remap)
-  int spmv_chunk = 8, spmv_nt = 1, spmv_xcd = 0, spmv_span = 1;
+  // SpMV variant (tuning knob, env SIM3OPT_SPMV="chunk,nt"; defaults chosen by measurement,
+  // scripts/gpu_spmv_ab.py: 8 blocks per pipeline step, non-temporal block stream)
+  int spmv_chunk = 8, spmv_nt = 1;
 
-  int spmv_grid() const {
-    if (spmv_span || comm.active()) return span_grid;
-    int g = grid_for(nb, 4);
-    return (g + 7) & ~7;  // multiple of 8: one share per XCD
-  }
+  int spmv_grid() const { return span_grid; }
 
-  void spmv_raw(double lambda, const DevScalars* scp) {
+  // q = (H + lambda I) v; partials of v.q in d_part_a and, with rvec, of rvec.v in d_part_b
+  void spmv_raw(double lambda, const double* v, double* q, const double* rvec, DevScalars* scp) {
     const int g = spmv_grid();
-    if (spmv_span || comm.active()) {
 #define SPAN_CASE(CH, NTV)                                                                      \
   hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
-                     d_colidx, d_vals, d_p, d_q, lambda, d_part_a, scp)
-      if (spmv_chunk <= 4) { if (spmv_nt) SPAN_CASE(4, true); else SPAN_CASE(4, false); }
-      else { if (spmv_nt) SPAN_CASE(8, true); else SPAN_CASE(8, false); }
+                     d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp)
+    if (spmv_chunk <= 4) { if (spmv_nt) SPAN_CASE(4, true); else SPAN_CASE(4, false); }
+    else { if (spmv_nt) SPAN_CASE(8, true); else SPAN_CASE(8, false); }
 #undef SPAN_CASE
-      return;
-    }
-#define SPMV_CASE(CH, NTV)                                                                    \
-  hipLaunchKernelGGL((k_spmv<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_rowptr, d_colidx, \
-                     d_vals, d_p, d_q, lambda, d_part_a, scp, spmv_xcd)
-    if (spmv_chunk <= 4) { if (spmv_nt) SPMV_CASE(4, true); else SPMV_CASE(4, false); }
-    else { if (spmv_nt) SPMV_CASE(8, true); else SPMV_CASE(8, false); }
-#undef SPMV_CASE
   }
 
-  int spmv_launch(double lambda, bool in_pcg, std::string& err) {
+  int spmv_launch(double lambda, std::string& err) {  // the PCG's SpMV: w = A z, w.z, r.z
     hipEvent_t a = nullptr, b = nullptr;
     if (opt.time_kernels) {
       int rc = pool_get(a, b, err);
       if (rc) return rc;
       HIPCHK(hipEventRecord(a, stream));
     }
-    spmv_raw(lambda, in_pcg ? d_sc : nullptr);
+    spmv_raw(lambda, d_z, d_q, d_r, d_sc);
     if (opt.time_kernels) HIPCHK(hipEventRecord(b, stream));
     return SIM3OPT_OK;
   }
 
-  // block-Jacobi PCG on (H + lambda I) x = b; result stays in d_x.
+  // Preconditioned CG on (H + lambda I) x = b in the single-reduction form (k_pcg_step); the
+  // result stays in d_x.  Two launches and one reduction point per iteration; the host only polls
+  // a 100-byte struct every `pcg_check_every` iterations.
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
+    if (use_chain) {
+      // the block-tridiagonal factorisation can meet a non-positive pivot when H is numerically
+      // semi-definite (cond ~1e12 in the reference's as-written arithmetic): retry with block-Jacobi
+      bool chain_broke = false;
+      int rc = pcg_attempt(lambda, true, iters, rel_res, ok, &chain_broke, err);
+      if (rc || !chain_broke) return rc;
+    }
+    return pcg_attempt(lambda, false, iters, rel_res, ok, nullptr, err);
+  }
+
+  int pcg_attempt(double lambda, bool use_chain, int32_t* iters, double* rel_res, bool* ok,
+                  bool* chain_broke, std::string& err) {
     const int nloc = r1 - r0;
     const int gj = std::max(1, (nloc + WG - 1) / WG);
     const int gv = grid_for((nloc + 8) / 9, 4);  // 36 block rows per workgroup pass
     const int gs = spmv_grid();
-    const int ge = grid_for(7 * (int64_t)nloc, WG);
     const bool multi = comm.active();
-    const double* pq_s = multi ? &d_sc->tmp_pq : nullptr;
-    const double* rz_s = multi ? &d_sc->tmp_rz : nullptr;
-    int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
-    const double tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
-    int rc = SIM3OPT_OK;
-    HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
+    const double* scal = multi ? &d_sc->tmp_pq : nullptr;  // [w.z, r.z] after the all-reduce
+    const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
     const int nseg = (nloc + chain_seg - 1) / chain_seg;
-    const int gc = grid_for(nseg, 4);             // chain apply: one wavefront per segment
-    const int gz = use_chain ? gc : gv;           // number of r.z partials
+    const int gc = grid_for(nseg, 4);  // chain apply: one wavefront per segment
     const double* Minv_arg = use_chain ? nullptr : d_Minv;
-    if (use_chain) {
+    int rc = SIM3OPT_OK;
+    h_sc->rz[0] = h_sc->rz[1] = h_sc->alpha[0] = h_sc->alpha[1] = h_sc->rz0 = 0.0;
+    h_sc->iter = 0;
+    h_sc->max_iter = max_it;
+    h_sc->done = h_sc->stop = h_sc->fail = 0;
+    h_sc->tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
+    // chi2 / scale / maxdiag live in the same struct: only the PCG fields are reset
+    HIPCHK(hipMemcpyAsync(&d_sc->rz[0], &h_sc->rz[0], offsetof(DevScalars, chi2), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(&d_sc->iter, &h_sc->iter, offsetof(DevScalars, tmp_pq) - offsetof(DevScalars, iter),
+                          hipMemcpyHostToDevice, stream));
+    if (use_chain)
       hipLaunchKernelGGL(k_chain_factor, dim3(std::max(1, (nseg + 63) / 64)), dim3(64), 0, stream,
                          r0, r1, chain_seg, d_rowptr, d_vals, d_sub_first, d_sub_cnt, lambda,
                          d_Minv, d_Gm, d_sc);
-      hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x,
-                         d_r, d_z, d_p, d_part_b);
-      hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
-                         d_Gm, d_r, d_z, d_p, d_part_b, (const DevScalars*)nullptr);
-    } else {
+    else
       hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, r0, r1, d_rowptr, d_vals, lambda,
                          d_Minv, d_sc);
-      hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x,
-                         d_r, d_z, d_p, d_part_b);
-    }
-    if (multi) {
-      hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gz, &d_sc->tmp_rz);
-      rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x, d_r,
+                       d_z, d_p, d_s);
+    if (use_chain) {
+      rc = fetch_scalars(err);  // did the factorisation succeed?
       if (rc) return rc;
-      rc = comm.allgatherv(d_p, offs, stream, err);
-      if (rc) return rc;
+      if (h_sc->fail) {
+        if (chain_broke) *chain_broke = true;
+        *ok = false;
+        *iters = 0;
+        *rel_res = 0.0;
+        return SIM3OPT_OK;
+      }
+      hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
+                         d_Gm, d_r, d_z, (const DevScalars*)nullptr);
     }
-    hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(WG), 0, stream, d_part_b, gz, d_sc, max_it,
-                       tol2, rz_s);
     HIPCHK(hipGetLastError());
+    if (multi) {
+      rc = comm.allgatherv(d_z, offs, stream, err);
+      if (rc) return rc;
+    }
     const int chunk = std::max(1, opt.pcg_check_every);
     int it = 0, par = 0;
     for (;;) {
@@ -1371,33 +1271,24 @@ class Engine {
         rc = pool_drain(err);
         if (rc) return rc;
       }
-      if (h_sc->done || h_sc->fail || it >= max_it) break;
+      if (h_sc->done || h_sc->stop || h_sc->fail || it >= max_it) break;
       const int todo = std::min(chunk, max_it - it);
       for (int c = 0; c < todo; ++c) {
-        rc = spmv_launch(lambda, true, err);
+        rc = spmv_launch(lambda, err);
         if (rc) return rc;
-        if (multi) {
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gs,
-                             &d_sc->tmp_pq);
-          rc = comm.allreduce(&d_sc->tmp_pq, 1, 0, stream, err);
+        if (multi) {  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent), one 2-double all-reduce
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gs, &d_sc->tmp_pq);
+          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gs, &d_sc->tmp_rz);
+          rc = comm.allreduce(&d_sc->tmp_pq, 2, 0, stream, err);
           if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_pcg_update1, dim3(gv), dim3(WG), 0, stream, r0, r1, par, pq_s,
-                           d_part_a, gs, Minv_arg, d_p, d_q, d_x, d_r, d_z, d_part_b, d_sc);
+        hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(WG), 0, stream, r0, r1, par, it, scal,
+                           d_part_a, d_part_b, gs, Minv_arg, d_z, d_q, d_p, d_s, d_x, d_r, d_sc);
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
-                             d_Minv, d_Gm, d_r, d_z, (double*)nullptr, d_part_b,
-                             (const DevScalars*)d_sc);
-        if (multi) {
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gz,
-                             &d_sc->tmp_rz);
-          rc = comm.allreduce(&d_sc->tmp_rz, 1, 0, stream, err);
-          if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_pcg_update2, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, par, rz_s,
-                           d_part_b, gz, d_z, d_p, d_sc);
-        if (multi) {
-          rc = comm.allgatherv(d_p, offs, stream, err);
+                             d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
+        if (multi) {  // the next SpMV gathers z from every rank
+          rc = comm.allgatherv(d_z, offs, stream, err);
           if (rc) return rc;
         }
         par ^= 1;
@@ -1411,8 +1302,8 @@ class Engine {
     }
     kt.n_pcg_vec += h_sc->iter;
     *iters = h_sc->iter;
-    const double rzf = h_sc->rz[h_sc->iter & 1];
-    *rel_res = h_sc->rz0 > 0 ? std::sqrt(std::fabs(rzf) / h_sc->rz0) : 0.0;
+    // r.z seen by the last executed step, i.e. of the residual BEFORE that step's update
+    *rel_res = h_sc->rz0 > 0 ? std::sqrt(std::fabs(h_sc->gam_last) / h_sc->rz0) : 0.0;
     *ok = !h_sc->fail;
     return SIM3OPT_OK;
   }
@@ -1637,9 +1528,9 @@ int engine_bench_spmv(Engine* e, int32_t reps, double* ms_mean, std::string& err
   // p = b as a representative dense vector
   HIPCHK(hipMemcpyAsync(e->d_p, e->d_b, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToDevice,
                         e->stream));
-  for (int i = 0; i < 3; ++i) e->spmv_raw(0.0, nullptr);
+  for (int i = 0; i < 3; ++i) e->spmv_raw(0.0, e->d_p, e->d_q, e->d_b, nullptr);
   HIPCHK(hipEventRecord(e->ev_a, e->stream));
-  for (int i = 0; i < reps; ++i) e->spmv_raw(0.0, nullptr);
+  for (int i = 0; i < reps; ++i) e->spmv_raw(0.0, e->d_p, e->d_q, e->d_b, nullptr);
   HIPCHK(hipEventRecord(e->ev_b, e->stream));
   HIPCHK(hipEventSynchronize(e->ev_b));
   float ms = 0.f;
