@@ -187,11 +187,12 @@ def main():
     if rank == 0:
         K = args.steps
         # algorithmic bytes of one SpMV launch: blocks + column indices + row
-        # pointers, p read once, q written once; per rank when row-partitioned
+        # pointers, the input vector read once, q written once; per rank when row-partitioned
         lo, hi = G.local_rows()  # rank 0's share (ranks are balanced by stored blocks)
         rows_local = hi - lo
         blocks_local = nnzb if world == 1 else (nnzb + world - 1) // world
-        spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 2 * 7 * rows_local * 8
+        # (the PCG's SpMV also reads r once for the fused r.z reduction)
+        spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 3 * 7 * rows_local * 8
         # HBM bytes per SpMV launch from the last rocprofv3 --pmc collection (separate passes;
         # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r1_pmc_spmv.json
         traffic = None
@@ -205,7 +206,7 @@ def main():
         if kt.n_spmv > 0:
             avg_ms = kt.ms_spmv / kt.n_spmv
             ach = spmv_bytes / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_spmv", "achieved": ach, "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": "k_spmv_span", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_ms": avg_ms, "launches": int(kt.n_spmv),
                     "algorithmic_bytes_per_launch": int(spmv_bytes)}

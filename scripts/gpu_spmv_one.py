@@ -9,7 +9,7 @@ G = L.Graph(fix_small_angle_b=1); G.add_vertices(g['states'], g['fixed']); G.add
 G.linearize()
 nb, nnzb = G.system_dims()
 ms = G.bench_spmv(int(os.environ.get("REPS", "10")))
-print("ms", ms, "alg bytes", nnzb * 396 + (nb + 1) * 4 + 2 * 7 * nb * 8)
+print("ms", ms, "alg bytes", nnzb * 396 + (nb + 1) * 4 + 3 * 7 * nb * 8)
 for mode in (0, 1, 2, 0, 1, 2):
     ms = G.bench_stream(mode, 30)
     print("stream mode", mode, "ms %.4f" % ms, "GB/s %.0f" % (nnzb * 392 / ms / 1e6))
