@@ -18,6 +18,7 @@
 //   PCG vectors x r z p q b: 7*nb each; Minv nb x 49 row-major
 // Assembly is atomic-free and reduction orders are fixed, so results are bitwise reproducible.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -1177,11 +1178,15 @@ class Engine {
   int spmv_grid() const { return span_grid; }
 
   // q = (H + lambda I) v; partials of v.q in d_part_a and, with rvec, of rvec.v in d_part_b
-  void spmv_raw(double lambda, const double* v, double* q, const double* rvec, DevScalars* scp) {
+  // With a start/stop event pair the dispatch itself is timestamped (hipExtLaunchKernelGGL):
+  // no extra barrier packets, so the figure agrees with rocprofv3's kernel trace.
+  void spmv_raw(double lambda, const double* v, double* q, const double* rvec, DevScalars* scp,
+                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const int g = spmv_grid();
-#define SPAN_CASE(CH, NTV)                                                                      \
-  hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
-                     d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp)
+#define SPAN_CASE(CH, NTV)                                                                       \
+  hipExtLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb,   \
+                        d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,        \
+                        d_part_b, scp)
     if (spmv_chunk <= 4) { if (spmv_nt) SPAN_CASE(4, true); else SPAN_CASE(4, false); }
     else { if (spmv_nt) SPAN_CASE(8, true); else SPAN_CASE(8, false); }
 #undef SPAN_CASE
@@ -1192,10 +1197,8 @@ class Engine {
     if (opt.time_kernels) {
       int rc = pool_get(a, b, err);
       if (rc) return rc;
-      HIPCHK(hipEventRecord(a, stream));
     }
-    spmv_raw(lambda, d_z, d_q, d_r, d_sc);
-    if (opt.time_kernels) HIPCHK(hipEventRecord(b, stream));
+    spmv_raw(lambda, d_z, d_q, d_r, d_sc, a, b);
     return SIM3OPT_OK;
   }
 
