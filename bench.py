@@ -97,8 +97,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
-    if args.transport == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+    if args.transport == "gloo" or os.environ.get("SIM3OPT_BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()  # dry runs: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

@@ -7,10 +7,10 @@ from sim3opt_amd import lib as L, synth
 synth.DRIFT_TARGET = 0.05
 g = synth.manhattan()
 res = {}
-variants = ["8,1,0,0", "8,1,0,1", "4,1,0,1", "8,0,0,1", "4,1,0,0"]
+variants = ["1024", "2048", "3072", "4096", "1536"]
 for rep in range(2):
     for v in variants:
-        os.environ["SIM3OPT_SPMV"] = v
+        os.environ["SIM3OPT_SPAN_GRID"] = v
         G = L.Graph(fix_small_angle_b=1); G.add_vertices(g['states'], g['fixed']); G.add_edges(g['v0'], g['v1'], g['meas']); G.initialize()
         G.linearize()
         nb, nnzb = G.system_dims()

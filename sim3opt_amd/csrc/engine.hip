@@ -1010,7 +1010,9 @@ class Engine {
     HIPCHK(upload(d_incptr, s.incptr));
     {  // span SpMV: contiguous row span per wavefront, balanced by stored blocks
       const int nloc = r1 - r0;
-      span_grid = std::max(8, std::min(MAX_GRID, (nloc + 15) / 16));
+      int span_cap = 2048;  // 256 CUs x 8 workgroups of 4 wavefronts: all resident at once
+      if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) span_cap = std::max(8, std::min(MAX_GRID, std::atoi(ev)));  // tuning knob (no effect measured)
+      span_grid = std::max(8, std::min(span_cap, (nloc + 15) / 16));
       const int nw = span_grid * 4;
       std::vector<int32_t> wrow(nw + 1);
       partition_rows(nloc, s.rowptr.data() + r0, nw, wrow.data());
