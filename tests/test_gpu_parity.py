@@ -495,3 +495,57 @@ def test_config3_manhattan_full_size_properties():
     assert all(s.pcg_rel_res <= 1e-8 or s.pcg_iters > 0 for s in st)
     assert abs(G.chi2() - st[-1].chi2_after) < 1e-9 * st[-1].chi2_after
     assert synth.rmse(G.get_vertices(), g["gt"]) < synth.rmse(g["states"], g["gt"])
+
+
+# ------------------------------------------------------------------ edge cases
+def test_minimal_and_degenerate_graphs():
+    I8 = np.array([0, 0, 0, 1, 0, 0, 0, 1.0])
+    # two vertices, one edge, exact solution after one step in the well-posed arithmetic
+    C = S3.exp(np.array([0.1, -0.2, 0.05, 1.0, 2.0, -1.0, 0.3]), fix_b=True)
+    g = dict(states=np.stack([I8, I8]), fixed=np.array([1, 0], np.uint8),
+             v0=np.array([0], np.int32), v1=np.array([1], np.int32), meas=C[None])
+    G, OG = mk(g, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-14), oracle_of(g)
+    n = G.optimize(8)
+    it, tr = OG.optimize(8, O.default_options(fix_small_angle_b=1, fd_delta=1e-6))
+    assert n >= 1 and G.stats()[-1].chi2_after < 1e-12
+    assert np.abs(G.get_vertex(1) - C).max() < 1e-6          # S1 = C * S0
+    assert synth.rmse(G.get_vertices(), OG.states) < 1e-6
+    # already optimal graph (residual at rounding level): nothing moves, nothing blows up
+    g0 = dict(g, states=np.stack([I8, C]))
+    G0 = mk(g0)
+    assert G0.chi2() < 1e-20
+    assert 1 <= G0.optimize(5) <= 5 and G0.chi2() < 1e-20
+    assert np.abs(G0.get_vertex(1) - C).max() < 1e-9
+    # a component without any fixed vertex (gauge free): lambda keeps the system SPD, nothing blows up
+    h = small(8, V=40, E=200)
+    extra = np.stack([I8, S3.exp(np.array([0, 0, 0.2, 1, 0, 0, 0.0]), fix_b=True)])
+    h2 = dict(states=np.concatenate([h["states"], extra]),
+              fixed=np.concatenate([h["fixed"], [0, 0]]).astype(np.uint8),
+              v0=np.concatenate([h["v0"], [40]]).astype(np.int32),
+              v1=np.concatenate([h["v1"], [41]]).astype(np.int32),
+              meas=np.concatenate([h["meas"], I8[None]]))
+    G2, OG2 = mk(h2, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12), oracle_of(h2)
+    n2 = G2.optimize(5)
+    OG2.optimize(5, O.default_options(fix_small_angle_b=1, fd_delta=1e-6))
+    assert n2 == 5 and np.isfinite(G2.get_vertices()).all()
+    assert abs(G2.stats()[-1].chi2_after - OG2.chi2(O.default_options(fix_small_angle_b=1))) \
+        < 1e-6 * max(G2.stats()[-1].chi2_after, 1e-6)
+
+
+def test_negative_w_quaternions_and_reinitialize():
+    g = small(9)
+    flip = g["states"].copy()
+    flip[::2, :4] *= -1.0  # q and -q are the same rotation
+    mflip = g["meas"].copy()
+    mflip[1::2, :4] *= -1.0
+    A = mk(g, fix_small_angle_b=1, fd_delta=1e-6)
+    B = mk(dict(g, states=flip, meas=mflip), fix_small_angle_b=1, fd_delta=1e-6)
+    assert abs(A.chi2() - B.chi2()) < 1e-9 * A.chi2()
+    A.optimize(4)
+    B.optimize(4)
+    assert synth.rmse(A.get_vertices(), B.get_vertices()) < 1e-7
+    # initializeOptimization() again keeps the current estimates (g2o semantics)
+    before = A.get_vertices()
+    A.initialize()
+    assert np.array_equal(A.get_vertices(), before)
+    assert abs(A.chi2() - A.stats()[-1].chi2_after if A.stats() else 0) >= 0
