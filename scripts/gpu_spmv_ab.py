@@ -1,4 +1,6 @@
-"""A/B of the SpMV variants on the config-3 matrix (one process, back to back)."""
+"""A/B of SpMV tuning knobs on the config-3 matrix (one process, back to back).
+Knobs are environment variables read at sim3opt_initialize: SIM3OPT_SPMV="chunk,nt" and
+SIM3OPT_SPAN_GRID=<workgroups>; edit `variants` / the variable name below for the knob under test."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
