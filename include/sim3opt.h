@@ -207,6 +207,24 @@ int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one
  * precision: 17 significant digits (the reference prints 6). image_ids may be NULL. */
 int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids);
 
+/* ---- interchange formats and map re-anchoring ----
+ * KeyFrame .bin reader: LoadComboKeyFrame                            drawPTAMPoints.cpp:33-84
+ * Two-call pattern: with capacity < *n_obs only the header (id, Rw2c row-major, twinc, n_obs) is
+ * returned; point_ids / points_w (n x 3) / obs_uv (n x 2) are filled when capacity >= n_obs. */
+int sim3opt_read_keyframe_bin(const char* path, int32_t* kf_id, double Rw2c[9], double twinc[3],
+                              int32_t* n_obs, uint32_t* point_ids, double* points_w, double* obs_uv,
+                              int32_t capacity);
+/* figureKITTIBA's re-anchoring                                        drawPTAMPoints.cpp:416-429
+ * points[k] <- S_new(f)^-1 * (R_old(f) points[k] + t_old(f)), f = keyframe of the point's LAST
+ * observation in (obs_frame, obs_point) order; unobserved points keep their coordinates.
+ * old_Rt: n_frames x 12 (R row-major, then t); new_states: n_frames x 8 (S_iw).  Runs on the GPU. */
+int sim3opt_reanchor_points(int32_t n_frames, const double* old_Rt, const double* new_states,
+                            int32_t n_points, double* points, int32_t n_obs,
+                            const int32_t* obs_frame, const int32_t* obs_point, int32_t device);
+/* g2o text export (VERTEX_SIM3:EXPMAP / EDGE_SIM3:EXPMAP / FIX) of a graph with ids 0..n-1 and
+ * identity information, for re-running it in stock g2o */
+int sim3opt_write_g2o(sim3opt_graph* g, const char* path);
+
 /* ---- stepwise optimisation, stage 1 (host C++) ----
  * "scale_dlt" of testStepwiseSim3Optimization                        kitti_surf.cpp:887-933
  * Null vector of the edge equations s_C x[v0] - x[v1] = 0 (the reference: last column of V of

@@ -112,6 +112,11 @@ SYMBOLS = {
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
     "sim3opt_stepwise_scale_init": (C.c_int, [_vp, _dp]),
+    "sim3opt_read_keyframe_bin": (C.c_int, [C.c_char_p, _ip, _dp, _dp, _ip, C.POINTER(C.c_uint32), _dp,
+                                            _dp, C.c_int32]),
+    "sim3opt_reanchor_points": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip,
+                                          C.c_int32]),
+    "sim3opt_write_g2o": (C.c_int, [_vp, C.c_char_p]),
     "sim3opt_align_trajectory": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _dp]),
 }
 
@@ -404,9 +409,48 @@ class Graph:
         self._chk(self._L.sim3opt_stepwise_scale_init(self._g, C.byref(r)))
         return r.value
 
+    def write_g2o(self, path):
+        self._chk(self._L.sim3opt_write_g2o(self._g, os.fsencode(path)))
+
     def write_poses(self, path, image_ids=None):
         ids = None if image_ids is None else _i32(image_ids)
         self._chk(self._L.sim3opt_write_poses(self._g, os.fsencode(path), _p(ids, _ip)))
+
+
+def read_keyframe_bin(path):
+    """dict(kf_id, Rw2c 3x3, twinc, point_ids, points_w (n,3), obs_uv (n,2))  -- LoadComboKeyFrame."""
+    Lb = load()
+    kf, n = C.c_int32(), C.c_int32()
+    R, t = np.empty(9), np.empty(3)
+    rc = Lb.sim3opt_read_keyframe_bin(os.fsencode(path), C.byref(kf), _p(R, _dp), _p(t, _dp),
+                                      C.byref(n), None, None, None, 0)
+    if rc != OK:
+        raise Sim3OptError(rc, "read_keyframe_bin")
+    ids = np.empty(max(n.value, 1), dtype=np.uint32)
+    pts = np.empty((max(n.value, 1), 3))
+    uv = np.empty((max(n.value, 1), 2))
+    rc = Lb.sim3opt_read_keyframe_bin(os.fsencode(path), C.byref(kf), _p(R, _dp), _p(t, _dp),
+                                      C.byref(n), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      _p(pts, _dp), _p(uv, _dp), n.value)
+    if rc != OK:
+        raise Sim3OptError(rc, "read_keyframe_bin")
+    k = n.value
+    return dict(kf_id=kf.value, Rw2c=R.reshape(3, 3), twinc=t, point_ids=ids[:k], points_w=pts[:k],
+                obs_uv=uv[:k])
+
+
+def reanchor_points(old_Rt, new_states, points, obs_frame, obs_point, device=-1):
+    """figureKITTIBA's point re-anchoring on the GPU; returns the corrected (n_points, 3) array."""
+    rt = _f64(old_Rt).reshape(-1, 12)
+    st = _f64(new_states).reshape(-1, 8)
+    pts = _f64(points).reshape(-1, 3).copy()
+    of, op = _i32(obs_frame), _i32(obs_point)
+    rc = load().sim3opt_reanchor_points(rt.shape[0], _p(rt, _dp), _p(st, _dp), pts.shape[0],
+                                        _p(pts, _dp), of.shape[0], _p(of, _ip), _p(op, _ip),
+                                        int(device))
+    if rc != OK:
+        raise Sim3OptError(rc, "reanchor_points")
+    return pts
 
 
 def align_trajectory(query_xyz, train_xyz, with_scale=True):
