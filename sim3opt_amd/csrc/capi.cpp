@@ -235,6 +235,8 @@ int sim3opt_initialize(sim3opt_graph* g) {
   if (g->initialized) {  // g2o allows re-initialisation: rebuild from the current estimates
     int rc = sync_host_states(g);
     if (rc) return rc;
+    engine_take_comm(g->engine, &g->comm);  // a multi-GPU graph stays partitioned after re-init
+    g->comm_set = g->comm.world > 1 || g->comm.force;
     engine_destroy(g->engine);
     g->engine = nullptr;
     g->initialized = false;

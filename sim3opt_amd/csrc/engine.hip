@@ -1435,6 +1435,11 @@ Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_opti
 
 void engine_destroy(Engine* e) { delete e; }
 
+void engine_take_comm(Engine* e, Comm* out) {
+  *out = e->comm;   // the caller owns the communicator again (re-initialisation keeps the ranks)
+  e->comm = Comm();
+}
+
 int engine_set_options(Engine* e, const sim3opt_options& opt) {
   const int dev = e->opt.device;
   e->opt = opt;

@@ -22,6 +22,8 @@ Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_opti
                       Comm* comm, std::string& err, int& status);
 void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end);
 void engine_destroy(Engine* e);
+// hands the communicator back before the engine is destroyed (re-initialisation)
+void engine_take_comm(Engine* e, Comm* out);
 
 int engine_set_options(Engine* e, const sim3opt_options& opt);
 int engine_optimize(Engine* e, int32_t max_iters, std::vector<sim3opt_iter_stats>& stats,

@@ -42,7 +42,15 @@ def _worker(rank, world, port, out):
     chi0 = G.chi2()
     n = G.optimize(4)
     st = G.stats()
+    # g2o semantics: initializeOptimization() again (here: after growing the graph by a duplicate
+    # of edge 0) keeps the estimates AND the row partition
+    a, b, m = G.get_edge(0)
+    G.add_edge(a, b, m)
+    G.initialize()
+    assert G.local_rows()[1] - G.local_rows()[0] < G.system_dims()[0]
+    regrown_chi = G.chi2()
     np.savez(out + f".{rank}.npz", states=G.get_vertices(), chi0=chi0, n=n, rows=[lo, hi],
+             regrown_chi=regrown_chi,
              chi=[s.chi2_after for s in st], trials=[s.trials for s in st],
              pcg=[s.pcg_iters for s in st])
 
@@ -74,6 +82,7 @@ def test_two_process_row_partition_matches_single(tmp_path, world):
         # vs the single-process run: only summation order differs
         assert np.allclose(r["chi"], [s.chi2_after for s in st], rtol=1e-7)
         assert synth.rmse(r["states"], G.get_vertices()) < 1e-6
+        assert abs(float(r["regrown_chi"]) - float(res[0]["regrown_chi"])) < 1e-12 * float(res[0]["regrown_chi"])
 
 
 def test_rccl_transport_single_rank_selftest(monkeypatch):
