@@ -60,7 +60,7 @@ typedef struct sim3opt_options {
   int32_t dof_mask;         /* 127   bit d set = tangent component d ([w0 w1 w2 u0 u1 u2 s]) is
                                         optimised; cleared bits freeze it (0x78 = rotations frozen:
                                         the scale+translation stage, kitti_surf.cpp:1020-1024)    */
-  int32_t pcg_max_iters;    /* 0 = automatic: min(max(7*free vertices, 100), 1000)       */
+  int32_t pcg_max_iters;    /* 0 = automatic: 2n for n = 7*free vertices <= 50000, else 1000 */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,

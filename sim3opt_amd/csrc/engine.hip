@@ -1226,7 +1226,10 @@ class Engine {
     const int gs = spmv_grid();
     const bool multi = comm.active();
     const double* scal = multi ? &d_sc->tmp_pq : nullptr;  // [w.z, r.z] after the all-reduce
-    const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : std::min(std::max(n, 100), 1000);
+    // automatic cap: small systems may need ~n iterations for an (almost) exact step like the
+    // reference's Cholesky (chains are ill-conditioned); large ones get a truncated-Newton budget
+    const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters
+                                             : (n <= 50000 ? std::max(100, 2 * n) : 1000);
     const int nseg = (nloc + chain_seg - 1) / chain_seg;
     const int gc = grid_for(nseg, 4);  // chain apply: one wavefront per segment
     const double* Minv_arg = use_chain ? nullptr : d_Minv;
