@@ -63,6 +63,8 @@ typedef struct sim3opt_options {
   int32_t pcg_max_iters;    /* 0 = automatic: 2n for n = 7*free vertices <= 50000, else 1000 */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
+  int32_t pcg_graph;        /* 1     replay the PCG iterations from a captured hipGraph (single GPU,
+                                        time_kernels = 0); 0 = enqueue every launch               */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
                                        -1 = automatic: chain for nearly pure chains (off-chain edges
                                        <= rows/64) in the well-posed arithmetic, else block-Jacobi  */

@@ -130,6 +130,7 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->pcg_max_iters = 0;
   o->pcg_rel_tol = 1e-10;
   o->pcg_check_every = 16;
+  o->pcg_graph = 1;
   o->preconditioner = -1;
   o->chain_segment = 256;
   o->device = -1;

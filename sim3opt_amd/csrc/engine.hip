@@ -45,6 +45,7 @@ using sim3::Sim3;
   } while (0)
 
 constexpr int WG = 256;         // 4 wavefronts of 64
+constexpr int PCG_GRAPH_ITERS = 16;  // PCG iterations per captured hipGraph (even: parity returns)
 constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
                                 // (256 CUs x 8 workgroups of 4 waves = full occupancy)
 
@@ -65,6 +66,7 @@ struct DevScalars {
   double tmp_pq;     // multi-GPU: w.z summed over ranks  } adjacent: ONE 2-double all-reduce
   double tmp_rz;     // multi-GPU: r.z summed over ranks  } per PCG iteration
   double gam_last;   // r.z seen by the last executed step (reported relative residual)
+  double lambda;     // damping of the current solve (read by the captured PCG launches)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -438,6 +440,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   __shared__ double sh[4];
   if (sc) {
     if (sc->done) return;
+    lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
     // the previous update was the last allowed one: later launches become no-ops
     if (blockIdx.x == 0 && threadIdx.x == 0 && sc->stop) sc->done = 1;
   }
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
   if (sc->done) return;
   const double delta = scal ? scal[0] : sum_partials(part_d, npart, sh);
   const double gamma = scal ? scal[1] : sum_partials(part_g, npart, sh);
-  const bool first = it == 0;
+  const bool first = it == 0;  // it < 0: a captured (replayed) launch, never the first iteration
   const double gamma0 = first ? gamma : sc->rz0;
   const bool commit = blockIdx.x == 0 && threadIdx.x == 0;
   if (!(gamma == gamma) || gamma < 0.0 || gamma <= sc->tol2 * gamma0 || (first && gamma == 0.0)) {
@@ -794,8 +797,9 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
     sc->rz[par ^ 1] = gamma;
     sc->gam_last = gamma;
     sc->alpha[par ^ 1] = alpha;
-    sc->iter = it + 1;
-    if (it + 1 >= sc->max_iter) sc->stop = 1;
+    const int itn = (it < 0 ? sc->iter : it) + 1;  // only this thread ever writes sc->iter
+    sc->iter = itn;
+    if (itn >= sc->max_iter) sc->stop = 1;
   }
 }
 
@@ -911,6 +915,9 @@ class Engine {
   double* d_Gm = nullptr;
   bool use_chain = false;
   int chain_seg = 256;
+  // hipGraph of PCG_GRAPH_ITERS iterations (single GPU, untimed runs): replayed per chunk
+  hipGraphExec_t pcg_graph = nullptr;
+  bool pcg_graph_chain = false;
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool linearized = false;
@@ -938,6 +945,7 @@ class Engine {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    if (pcg_graph) (void)hipGraphExecDestroy(pcg_graph);
     if (stream) (void)hipStreamDestroy(stream);
     comm.release();
   }
@@ -1189,8 +1197,17 @@ class Engine {
   hipExtLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb,   \
                         d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,        \
                         d_part_b, scp)
+#define SPAN_PLAIN(CH, NTV)                                                                     \
+  hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
+                     d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp)
+    if (!ev0) {  // plain launch: capturable into a hipGraph
+      if (spmv_chunk <= 4) { if (spmv_nt) SPAN_PLAIN(4, true); else SPAN_PLAIN(4, false); }
+      else { if (spmv_nt) SPAN_PLAIN(8, true); else SPAN_PLAIN(8, false); }
+      return;
+    }
     if (spmv_chunk <= 4) { if (spmv_nt) SPAN_CASE(4, true); else SPAN_CASE(4, false); }
     else { if (spmv_nt) SPAN_CASE(8, true); else SPAN_CASE(8, false); }
+#undef SPAN_PLAIN
 #undef SPAN_CASE
   }
 
@@ -1239,10 +1256,12 @@ class Engine {
     h_sc->max_iter = max_it;
     h_sc->done = h_sc->stop = h_sc->fail = 0;
     h_sc->tol2 = opt.pcg_rel_tol * opt.pcg_rel_tol;
+    h_sc->lambda = lambda;
     // chi2 / scale / maxdiag live in the same struct: only the PCG fields are reset
     HIPCHK(hipMemcpyAsync(&d_sc->rz[0], &h_sc->rz[0], offsetof(DevScalars, chi2), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(&d_sc->iter, &h_sc->iter, offsetof(DevScalars, tmp_pq) - offsetof(DevScalars, iter),
                           hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(&d_sc->lambda, &h_sc->lambda, sizeof(double), hipMemcpyHostToDevice, stream));
     if (use_chain)
       hipLaunchKernelGGL(k_chain_factor, dim3(std::max(1, (nseg + 63) / 64)), dim3(64), 0, stream,
                          r0, r1, chain_seg, d_rowptr, d_vals, d_sub_first, d_sub_cnt, lambda,
@@ -1272,6 +1291,29 @@ class Engine {
     }
     const int chunk = std::max(1, opt.pcg_check_every);
     int it = 0, par = 0;
+    // Launch-bound regime (small graphs: two ~3 us kernels per iteration): replay a captured
+    // hipGraph of PCG_GRAPH_ITERS iterations instead of enqueueing them one by one.  The first
+    // iteration stays eager (it carries it == 0); captured steps read the counter, the damping and
+    // the stopping state from DevScalars, so one instantiated graph serves every solve.
+    const bool graphed = !multi && !opt.time_kernels && opt.pcg_graph && max_it > PCG_GRAPH_ITERS;
+    if (graphed && (!pcg_graph || pcg_graph_chain != use_chain)) {
+      if (pcg_graph) { (void)hipGraphExecDestroy(pcg_graph); pcg_graph = nullptr; }
+      hipGraph_t gr = nullptr;
+      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      for (int c = 0; c < PCG_GRAPH_ITERS; ++c) {
+        spmv_raw(lambda, d_z, d_q, d_r, d_sc);
+        hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(WG), 0, stream, r0, r1, (1 + c) & 1, -1,
+                           (const double*)nullptr, d_part_a, d_part_b, gs, Minv_arg, d_z, d_q, d_p,
+                           d_s, d_x, d_r, d_sc);
+        if (use_chain)
+          hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
+                             d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
+      }
+      HIPCHK(hipStreamEndCapture(stream, &gr));
+      HIPCHK(hipGraphInstantiate(&pcg_graph, gr, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(gr);
+      pcg_graph_chain = use_chain;
+    }
     for (;;) {
       rc = fetch_scalars(err);
       if (rc) return rc;
@@ -1280,7 +1322,15 @@ class Engine {
         if (rc) return rc;
       }
       if (h_sc->done || h_sc->stop || h_sc->fail || it >= max_it) break;
-      const int todo = std::min(chunk, max_it - it);
+      if (graphed && it > 0 && par == 1 && max_it - it >= PCG_GRAPH_ITERS) {
+        // steps past max_iter cannot happen: the step that reaches it raises `stop`, and the
+        // following launches of the replay are no-ops
+        const int reps = std::max(1, std::min(chunk, max_it - it) / PCG_GRAPH_ITERS);
+        for (int k = 0; k < reps; ++k) HIPCHK(hipGraphLaunch(pcg_graph, stream));
+        it += reps * PCG_GRAPH_ITERS;
+        continue;
+      }
+      const int todo = graphed && it == 0 ? 1 : std::min(chunk, max_it - it);
       for (int c = 0; c < todo; ++c) {
         rc = spmv_launch(lambda, err);
         if (rc) return rc;

@@ -33,6 +33,7 @@ class Options(C.Structure):
         ("pcg_max_iters", C.c_int32),
         ("pcg_rel_tol", C.c_double),
         ("pcg_check_every", C.c_int32),
+        ("pcg_graph", C.c_int32),
         ("preconditioner", C.c_int32),
         ("chain_segment", C.c_int32),
         ("device", C.c_int32),
