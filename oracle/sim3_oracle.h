@@ -14,8 +14,9 @@
  * formula authority sim3_rv.h for exp/log.  What pins it is listed in
  * tests/test_oracle.py: the reference's input data files, the by-construction
  * zero residual of odometry edges (kitti_surf.cpp:653-666), the loop scale
- * ln(5.32393351) (loopConstraints.txt record 1), group identities, and an
- * independent numpy/scipy restatement (oracle/crosscheck_numpy.py).
+ * ln(5.32393351) (loopConstraints.txt record 1), group identities, closed-form
+ * Jacobians, dense numpy linear algebra, and an independent numpy restatement of
+ * the Sim(3) formulae (sim3opt_amd/sim3np.py, used only to prepare data).
  */
 #ifndef SIM3_ORACLE_H
 #define SIM3_ORACLE_H
