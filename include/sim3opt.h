@@ -39,7 +39,6 @@ enum {
 };
 
 enum { SIM3OPT_KERNEL_NONE = 0, SIM3OPT_KERNEL_HUBER = 1 };
-enum { SIM3OPT_JAC_NUMERIC = 0, SIM3OPT_JAC_ANALYTIC = 1 };
 
 /* Solver configuration.  Replaces the reference's
  *   OptimizationAlgorithmLevenberg(BlockSolverX(LinearSolverEigen))   kitti_surf.cpp:552-558
@@ -51,8 +50,8 @@ typedef struct sim3opt_options {
   double good_step_lower;   /* 1/3                                                       */
   double good_step_upper;   /* 2/3                                                       */
   int32_t max_trials;       /* 10    maxTrialsAfterFailure                               */
-  int32_t jacobian_mode;    /* SIM3OPT_JAC_NUMERIC (g2o default for EdgeSim3)            */
-  double fd_delta;          /* 1e-9  central-difference step of the numeric mode         */
+  double fd_delta;          /* 1e-9  central-difference step of the numeric Jacobians (g2o's
+                                        BaseBinaryEdge default; 1e-6 gives 1e-10-accurate Jacobians) */
   double exp_eps;           /* 1e-5  branch threshold of exp/log (sim3_rv.h:133)         */
   int32_t small_rot_half;   /* 0     R = I+W+W^2 (sim3_rv.h:151); 1: I+W+W^2/2           */
   int32_t fix_small_angle_b;/* 0     B coefficient as written in sim3_rv.h:166/:290 (reference

@@ -121,7 +121,6 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->good_step_lower = 1.0 / 3.0;
   o->good_step_upper = 2.0 / 3.0;
   o->max_trials = 10;
-  o->jacobian_mode = SIM3OPT_JAC_NUMERIC;
   o->fd_delta = 1e-9;
   o->exp_eps = 1e-5;
   o->small_rot_half = 0;

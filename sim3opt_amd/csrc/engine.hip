@@ -1150,10 +1150,6 @@ class Engine {
   }
 
   int linearize(std::string& err) {
-    if (opt.jacobian_mode != SIM3OPT_JAC_NUMERIC) {
-      err = "jacobian_mode: only SIM3OPT_JAC_NUMERIC is implemented";
-      return SIM3OPT_ERR_ARG;
-    }
     HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
     LinArgs A{n_active, d_active, d_ev0, d_ev1, d_meas, d_info, d_kdelta, d_states,
               d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts(),

@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libsim3opt.so")
 
 OK, ERR_ARG, ERR_STATE, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_NONE, KERNEL_HUBER = 0, 1
-JAC_NUMERIC, JAC_ANALYTIC = 0, 1
 
 
 class Options(C.Structure):
@@ -24,7 +23,6 @@ class Options(C.Structure):
         ("good_step_lower", C.c_double),
         ("good_step_upper", C.c_double),
         ("max_trials", C.c_int32),
-        ("jacobian_mode", C.c_int32),
         ("fd_delta", C.c_double),
         ("exp_eps", C.c_double),
         ("small_rot_half", C.c_int32),

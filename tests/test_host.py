@@ -31,7 +31,7 @@ def test_options_struct_matches_header_defaults():
     o = L.default_options()
     assert o.tau == 1e-5 and o.max_trials == 10 and o.fd_delta == 1e-9 and o.exp_eps == 1e-5
     assert abs(o.good_step_lower - 1 / 3) < 1e-16 and abs(o.good_step_upper - 2 / 3) < 1e-16
-    assert o.jacobian_mode == L.JAC_NUMERIC and o.fix_small_angle_b == 0 and o.device == -1
+    assert o.fix_small_angle_b == 0 and o.device == -1 and o.dof_mask == 127 and o.pcg_graph == 1
     # field-by-field agreement between the ctypes mirror and the C header
     hdr = open(os.path.join(ROOT, "include", "sim3opt.h")).read()
     body = hdr[hdr.index("typedef struct sim3opt_options {"):hdr.index("} sim3opt_options;")]
