@@ -177,8 +177,8 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
 
 /* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
- * Every rank adds the SAME full graph; rank r then owns a contiguous range of block rows (balanced by
- * stored 7x7 blocks), linearises the edges incident to them, streams its rows in the SpMV and keeps
+ * Every rank adds the SAME full graph; rank r then owns a contiguous range of block rows (equal
+ * length), linearises the edges incident to them, streams its rows in the SpMV and keeps
  * a replica of all vertex estimates.  Collectives per PCG iteration: one all-gather of the search
  * direction, two scalar all-reduces; per LM trial: one all-gather of the step, one 2-scalar
  * all-reduce.  All ranks return identical results.  Call between create and initialize.
@@ -196,7 +196,11 @@ typedef int (*sim3opt_allgatherv_fn)(void* ctx, double* buf, const int64_t* offs
 int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
                                 sim3opt_allreduce_fn allreduce, sim3opt_allgatherv_fn allgatherv,
                                 void* ctx);
-/* host-side partition plan (no GPU needed): first block row of each rank, size world+1 */
+/* host-side partition plans (no GPU needed), world+1 entries each:
+ *   _equal : the RANK partition -- equal-length row spans, so the per-iteration exchange is one
+ *            in-place ncclAllGather (pose-graph rows have near-uniform block counts)
+ *   plain  : spans balanced by stored 7x7 blocks (used for the SpMV's per-wavefront spans) */
+int sim3opt_partition_rows_equal(int32_t n_block_rows, int32_t world, int32_t* row_begin);
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin /*world+1*/);
 /* block-row range [begin, end) this graph's rank owns (valid after initialize) */

@@ -382,6 +382,12 @@ int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t 
   return SIM3OPT_OK;
 }
 
+int sim3opt_partition_rows_equal(int32_t n_block_rows, int32_t world, int32_t* row_begin) {
+  if (n_block_rows < 0 || world < 1 || !row_begin) return SIM3OPT_ERR_ARG;
+  partition_rows_equal(n_block_rows, world, row_begin);
+  return SIM3OPT_OK;
+}
+
 int sim3opt_comm_unique_id(uint8_t id_out[128]) {
   if (!id_out) return SIM3OPT_ERR_ARG;
   std::string err;

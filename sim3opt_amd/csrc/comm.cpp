@@ -20,6 +20,8 @@ struct RcclApi {
                             hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t,
                             hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -52,6 +54,7 @@ bool load_rccl(std::string& err) {
   LOAD(CommDestroy, "ncclCommDestroy")
   LOAD(AllReduce, "ncclAllReduce")
   LOAD(Broadcast, "ncclBroadcast")
+  LOAD(AllGather, "ncclAllGather")
   LOAD(GroupStart, "ncclGroupStart")
   LOAD(GroupEnd, "ncclGroupEnd")
   LOAD(GetErrorString, "ncclGetErrorString")
@@ -137,7 +140,17 @@ int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t
                      std::string& err) {
   if (!active()) return SIM3OPT_OK;
   if (kind == 1) {
-    // ranks own unequal spans (balanced by stored blocks), so one grouped broadcast per owner
+    // equal spans (the engine's partition; buffers are padded to world x count): ONE in-place
+    // ncclAllGather -- rank r's segment already sits at recvbuff + r * count
+    const int64_t cnt = offs[1] - offs[0];
+    bool equal = cnt > 0;
+    for (int r = 0; r < world && equal; ++r) equal = offs[r] == (int64_t)r * cnt || offs[r] == offs[world];
+    if (equal) {
+      NCCLCHK(g_api.AllGather(dvec + (int64_t)rank * cnt, dvec, (size_t)cnt, ncclFloat64,
+                              (ncclComm_t)nccl, stream));
+      return SIM3OPT_OK;
+    }
+    // general spans: one grouped broadcast per owner
     NCCLCHK(g_api.GroupStart());
     for (int r = 0; r < world; ++r) {
       const size_t cnt = (size_t)(offs[r + 1] - offs[r]);

@@ -33,7 +33,8 @@ struct Comm {
   // in-place on device memory, ordered on `stream`; op: 0 = sum, 1 = max
   int allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err);
   // in-place all-gather of a vector split at offs[0..world] (in doubles); rank r contributes
-  // [offs[r], offs[r+1])
+  // [offs[r], offs[r+1]).  With equal spans (offs[r] = r * count, short tail allowed) the buffer must
+  // hold world * count doubles: the RCCL transport then issues a single ncclAllGather
   int allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
                  std::string& err);
   void release();

@@ -978,7 +978,7 @@ class Engine {
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
     // row partition (world == 1: everything is local)
     row_begin.assign(comm.world + 1, 0);
-    partition_rows(nb, s.rowptr.data(), comm.world, row_begin.data());
+    partition_rows_equal(nb, comm.world, row_begin.data());
     r0 = row_begin[comm.rank];
     r1 = row_begin[comm.rank + 1];
     offs.resize(comm.world + 1);
@@ -1066,8 +1066,10 @@ class Engine {
     }
     double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q, &d_s};
     for (double** v : vecs) {
-      HIPCHK(hipMalloc((void**)v, sizeof(double) * (size_t)n));
-      HIPCHK(hipMemset(*v, 0, sizeof(double) * (size_t)n));
+      // padded to world x (7 x rows per rank) so the all-gather can run in place with equal counts
+      const size_t n_alloc = std::max<size_t>((size_t)n, (size_t)comm.world * (size_t)(offs[1] - offs[0]));
+      HIPCHK(hipMalloc((void**)v, sizeof(double) * n_alloc));
+      HIPCHK(hipMemset(*v, 0, sizeof(double) * n_alloc));
     }
     HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * MAX_GRID));
     HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * MAX_GRID));

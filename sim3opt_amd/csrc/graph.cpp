@@ -108,4 +108,11 @@ void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* b
     if (begin[r] < begin[r - 1]) begin[r] = begin[r - 1];
 }
 
+void partition_rows_equal(int32_t nb, int32_t world, int32_t* begin) {
+  // rank spans of equal length (the last ones may be short or empty): with 7*rows_per_rank
+  // doubles per rank the search-direction exchange is ONE in-place ncclAllGather
+  const int32_t rpr = (nb + world - 1) / world;
+  for (int32_t r = 0; r <= world; ++r) begin[r] = (int32_t)std::min<int64_t>((int64_t)r * rpr, nb);
+}
+
 }  // namespace sim3opt

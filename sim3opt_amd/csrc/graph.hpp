@@ -64,4 +64,7 @@ bool build_structure(const HostGraph& g, Structure& s, std::string& err);
 // Contiguous row partition balanced by stored blocks (multi-GPU row split); begin has world+1 entries.
 void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin);
 
+// Equal-length contiguous row spans (multi-GPU rank partition); begin has world+1 entries.
+void partition_rows_equal(int32_t nb, int32_t world, int32_t* begin);
+
 }  // namespace sim3opt

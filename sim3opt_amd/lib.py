@@ -108,6 +108,7 @@ SYMBOLS = {
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
+    "sim3opt_partition_rows_equal": (C.c_int, [C.c_int32, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
     "sim3opt_stepwise_scale_init": (C.c_int, [_vp, _dp]),
@@ -462,6 +463,14 @@ def align_trajectory(query_xyz, train_xyz, with_scale=True):
     if rc != OK:
         raise Sim3OptError(rc, "align_trajectory")
     return S.reshape(4, 4), rm.value, mx.value
+
+
+def partition_rows_equal(n_block_rows, world):
+    out = np.empty(world + 1, dtype=np.int32)
+    rc = load().sim3opt_partition_rows_equal(int(n_block_rows), int(world), _p(out, _ip))
+    if rc != OK:
+        raise Sim3OptError(rc, "partition_rows_equal")
+    return out
 
 
 def partition_rows(rowptr, world):

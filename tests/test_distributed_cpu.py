@@ -2,8 +2,8 @@
 
 The HIP kernels cannot run here, so this test executes the distributed ALGORITHM the engine uses
 (Engine::pcg in csrc/engine.hip, multi-GPU branch) in numpy, with the engine's own partition
-function (sim3opt_partition_rows through the C-ABI) and the same collectives in the same order --
-all-gather of p, all-reduce of p.q, all-reduce of r.z per iteration -- over torch.distributed gloo,
+function (sim3opt_partition_rows_equal through the C-ABI) and the same collectives in the same order --
+all-gather of z and one 2-double all-reduce of (w.z, r.z) per iteration -- over torch.distributed gloo,
 and checks it against a serial solve.  The real kernels run the same path with 2 processes on one
 GPU in tests/test_distributed_gpu.py.
 """
@@ -51,39 +51,40 @@ def _worker(rank, world, port, out):
     n = H.shape[0]
     lam = 1e-5 * np.abs(np.diag(H)).max()
     A = H + lam * np.eye(n)
-    beg = L.partition_rows(_rowptr_of(H), world)
+    beg = L.partition_rows_equal(n // 7, world)  # the engine's rank partition
     offs = (7 * beg).astype(np.int64)
     lo, hi = offs[rank], offs[rank + 1]
     Minv = np.zeros((n, n))
     for i in range(n // 7):
         Minv[7 * i:7 * i + 7, 7 * i:7 * i + 7] = np.linalg.inv(A[7 * i:7 * i + 7, 7 * i:7 * i + 7])
-    # local state
+    # local state; single-reduction PCG exactly as k_pcg_step does it
     x = np.zeros(n)
     r = np.zeros(n)
     r[lo:hi] = b[lo:hi]
     z = np.zeros(n)
     z[lo:hi] = Minv[lo:hi, lo:hi] @ r[lo:hi]
     p = np.zeros(n)
-    p[lo:hi] = z[lo:hi]
-    s = np.array([r[lo:hi] @ z[lo:hi]])
-    D.allreduce(s, 0)
-    rz = rz0 = s[0]
-    D.allgatherv(p, offs, rank)
-    it = 0
-    while rz > 1e-24 * rz0 and it < 2000:
-        q = A[lo:hi, :] @ p                      # this rank's block rows only
-        s = np.array([p[lo:hi] @ q])
-        D.allreduce(s, 0)
-        alpha = rz / s[0]
-        x[lo:hi] += alpha * p[lo:hi]
-        r[lo:hi] -= alpha * q
-        z[lo:hi] = Minv[lo:hi, lo:hi] @ r[lo:hi]
-        s = np.array([r[lo:hi] @ z[lo:hi]])
-        D.allreduce(s, 0)
-        beta = s[0] / rz
-        rz = s[0]
+    sv = np.zeros(n)
+    D.allgatherv(z, offs, rank)              # the SpMV gathers z from every rank
+    it, gamma_old, alpha_old, gamma0 = 0, 0.0, 0.0, 0.0
+    while it < 2000:
+        w = A[lo:hi, :] @ z                   # this rank's block rows only
+        s = np.array([w @ z[lo:hi], r[lo:hi] @ z[lo:hi]])
+        D.allreduce(s, 0)                     # ONE 2-double all-reduce per iteration
+        delta, gamma = s
+        if it == 0:
+            gamma0 = gamma
+        if gamma <= 1e-24 * gamma0:
+            break
+        beta = 0.0 if it == 0 else gamma / gamma_old
+        alpha = gamma / (delta if it == 0 else delta - beta * gamma / alpha_old)
         p[lo:hi] = z[lo:hi] + beta * p[lo:hi]
-        D.allgatherv(p, offs, rank)
+        sv[lo:hi] = w + beta * sv[lo:hi]
+        x[lo:hi] += alpha * p[lo:hi]
+        r[lo:hi] -= alpha * sv[lo:hi]
+        z[lo:hi] = Minv[lo:hi, lo:hi] @ r[lo:hi]
+        D.allgatherv(z, offs, rank)
+        gamma_old, alpha_old = gamma, alpha
         it += 1
     D.allgatherv(x, offs, rank)
     m = np.array([float(it)])
@@ -109,6 +110,9 @@ def test_partition_is_exhaustive_and_disjoint():
     H, _ = _block_system(1)
     rp = _rowptr_of(H)
     for world in (2, 3, 5):
+        eq = L.partition_rows_equal(len(rp) - 1, world)
+        assert eq[0] == 0 and eq[-1] == len(rp) - 1 and np.all(np.diff(eq) >= 0)
+        assert len(set(np.diff(eq)[:-1].tolist())) <= 1  # equal spans, short tail
         beg = L.partition_rows(rp, world)
         rows = np.concatenate([np.arange(beg[r], beg[r + 1]) for r in range(world)])
         assert np.array_equal(rows, np.arange(len(rp) - 1))
