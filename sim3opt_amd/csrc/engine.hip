@@ -99,6 +99,19 @@ __global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ par
   if (threadIdx.x == 0) *out = s;
 }
 
+// two sums in one launch (multi-GPU PCG: [w.z, r.z] land in adjacent doubles for one all-reduce)
+__global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa,
+                                                   const double* __restrict__ pb, int n,
+                                                   double* __restrict__ out2) {
+  __shared__ double sh[4];
+  const double a = sum_partials(pa, n, sh);
+  const double b = sum_partials(pb, n, sh);
+  if (threadIdx.x == 0) {
+    out2[0] = a;
+    out2[1] = b;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-edge residual kernels
 // ------------------------------------------------------------------------------------------
@@ -1333,8 +1346,8 @@ class Engine {
         rc = spmv_launch(lambda, err);
         if (rc) return rc;
         if (multi) {  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent), one 2-double all-reduce
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gs, &d_sc->tmp_pq);
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, gs, &d_sc->tmp_rz);
+          hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
+                             &d_sc->tmp_pq);
           rc = comm.allreduce(&d_sc->tmp_pq, 2, 0, stream, err);
           if (rc) return rc;
         }
