@@ -121,30 +121,45 @@ def main():
                 fix_small_angle_b=args.fix_small_angle_b)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
-    if world > 1 and args.transport == "gloo":
+    transport_used = None
+    if world > 1:
+        gloo_group = None
+
         def _ar(arr, op):
-            dist.all_reduce(torch.from_numpy(arr),
+            dist.all_reduce(torch.from_numpy(arr), group=gloo_group,
                             op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
 
         def _ag(arr, offs, rk):
             t = torch.from_numpy(arr)
             for r in range(len(offs) - 1):
                 if offs[r + 1] > offs[r]:
-                    dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r)
+                    dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r, group=gloo_group)
 
-        G.comm_init_callbacks(rank, world, _ar, _ag)
-    elif world > 1:
-        uid = np.zeros(128, dtype=np.uint8)
-        if rank == 0:
-            rc = L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up))
-            if rc != L.OK:
-                raise SystemExit("sim3opt_comm_unique_id failed")
-        t = torch.from_numpy(uid).cuda()
-        dist.broadcast(t, 0)
-        uid = np.ascontiguousarray(t.cpu().numpy())
-        rc = L.load().sim3opt_comm_init(G._g, rank, world, uid.ctypes.data_as(L._up))
-        if rc != L.OK:
-            raise SystemExit("sim3opt_comm_init: " + L.load().sim3opt_last_error(G._g).decode())
+        ok = 0
+        if args.transport == "rccl":
+            # the library builds its own RCCL communicator from an id broadcast over torch's group
+            uid = np.zeros(128, dtype=np.uint8)
+            ok = 1
+            if rank == 0 and L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) != L.OK:
+                ok = 0
+            t = torch.from_numpy(uid).cuda()
+            dist.broadcast(t, 0)
+            uid = np.ascontiguousarray(t.cpu().numpy())
+            if ok and L.load().sim3opt_comm_init(G._g, rank, world,
+                                                 uid.ctypes.data_as(L._up)) != L.OK:
+                sys.stderr.write("sim3opt_comm_init: " + L.load().sim3opt_last_error(G._g).decode() + "\n")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank must have its communicator
+            ok = int(flag.item())
+            transport_used = "rccl" if ok else None
+        if not ok:
+            # host-staged collectives over gloo: the dry-run transport, and the fallback should the
+            # library's RCCL communicator not come up on some rank (same partitioned kernels)
+            if args.transport != "gloo":
+                gloo_group = dist.new_group(backend="gloo")
+            G.comm_init_callbacks(rank, world, _ar, _ag)
+            transport_used = "gloo"
     G.initialize()  # uploads everything to HBM
     chi2_0 = G.chi2()
     nb, nnzb = G.system_dims()
@@ -224,7 +239,7 @@ def main():
                        "vertices": args.vertices, "edges": args.edges,
                        "fix_small_angle_b": args.fix_small_angle_b,
                        "parallelism": "single GPU" if world == 1 else f"row-partition x{world}",
-                       "transport": None if world == 1 else args.transport},
+                       "transport": transport_used},
             "edges_iters_per_s": args.edges * K / dt,
             "chi2_initial": chi2_0, "chi2_final": chi2_final,
             "lm_trials": [int(s.trials) for s in stats],
