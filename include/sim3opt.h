@@ -65,8 +65,12 @@ typedef struct sim3opt_options {
   int32_t pcg_graph;        /* 1     replay the PCG iterations from a captured hipGraph (single GPU,
                                         time_kernels = 0); 0 = enqueue every launch               */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
-                                       -1 = automatic: chain for nearly pure chains (off-chain edges
-                                       <= rows/64) in the well-posed arithmetic, else block-Jacobi  */
+                                       2 = aggregation multigrid V(1,1) cycle (pairwise-matched
+                                       aggregates, Ad(S_v)-transported prolongation; single GPU),
+                                       -1 = automatic, in the well-posed arithmetic only: chain for
+                                       nearly pure chains (off-chain edges <= rows/64), multigrid for
+                                       >= 20000 free vertices with >= 8 off-diagonal blocks per row,
+                                       else block-Jacobi                                           */
   int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */
   int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */
@@ -175,6 +179,13 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
 /* HBM read calibration over the same value array (bench only): mode 0 = 16 B/lane contiguous,
  * 1 = 8 B/lane contiguous, 2 = 8 B/lane on 49 of 64 lanes per 392-B block (the SpMV's shape) */
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
+/* Structure of the multigrid hierarchy `preconditioner = 2` would use for this graph (host only, no
+ * GPU needed, may be called before initialize): *n_levels levels; rows[l] / blocks[l] = block rows
+ * and stored 7x7 blocks of level l (up to `capacity` levels are written); aggregate_of_row (may be
+ * NULL) receives, for each level-0 block row (free vertex in insertion order), its level-1 row.
+ * SIM3OPT_ERR_STATE when the graph does not coarsen (block-Jacobi is used then). */
+int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels, int32_t* rows,
+                          int64_t* blocks, int32_t* aggregate_of_row);
 
 /* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
  * Every rank adds the SAME full graph; rank r then owns a contiguous range of block rows (equal

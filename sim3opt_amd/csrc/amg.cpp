@@ -1,0 +1,211 @@
+// amg.cpp -- pairwise-matching aggregation and Galerkin bookkeeping (see amg.hpp).
+#include "amg.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace sim3opt {
+
+namespace {
+
+struct WGraph {  // weighted adjacency without self loops, neighbours ascending
+  std::vector<int32_t> ptr, nbr;
+  std::vector<int64_t> wgt;
+  int32_t n() const { return (int32_t)ptr.size() - 1; }
+};
+
+// weight = number of level-0 blocks between two rows (parallel edges count); bw == nullptr: 1 each
+WGraph graph_from_pattern(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
+                          const int64_t* bw) {
+  WGraph g;
+  g.ptr.assign(nb + 1, 0);
+  for (int32_t i = 0; i < nb; ++i) {
+    int32_t last = -1;
+    for (int32_t k = rowptr[i] + 1; k < rowptr[i + 1]; ++k) {  // columns ascending after the diagonal
+      const int32_t j = colidx[k];
+      if (j == i) continue;
+      const int64_t w = bw ? bw[k] : 1;
+      if (j == last) {
+        g.wgt.back() += w;
+      } else {
+        g.nbr.push_back(j);
+        g.wgt.push_back(w);
+        last = j;
+      }
+    }
+    g.ptr[i + 1] = (int32_t)g.nbr.size();
+  }
+  return g;
+}
+
+// One pass of greedy heavy-edge matching in natural order; returns the number of clusters.
+int32_t match_pass(const WGraph& g, std::vector<int32_t>& cid) {
+  const int32_t m = g.n();
+  std::vector<int32_t> match(m, -1);
+  for (int32_t i = 0; i < m; ++i) {
+    if (match[i] >= 0) continue;
+    int32_t best = -1;
+    int64_t bw = 0;
+    for (int32_t k = g.ptr[i]; k < g.ptr[i + 1]; ++k) {
+      const int32_t j = g.nbr[k];
+      if (match[j] < 0 && g.wgt[k] > bw) {
+        best = j;
+        bw = g.wgt[k];
+      }
+    }
+    if (best >= 0) {
+      match[i] = best;
+      match[best] = i;
+    } else {
+      match[i] = i;
+    }
+  }
+  // rows left alone (all neighbours were taken when their turn came: leaves of hubs, odd ends of
+  // chains) join the neighbouring cluster they are tied to most strongly, up to 4 rows per
+  // cluster and pass -- otherwise star-like coarse graphs stop coarsening
+  std::vector<int32_t> rep(m), csize(m, 0);
+  for (int32_t i = 0; i < m; ++i) {
+    rep[i] = std::min(i, match[i]);
+    ++csize[rep[i]];
+  }
+  for (int32_t i = 0; i < m; ++i) {
+    if (match[i] != i) continue;
+    int32_t best = -1;
+    int64_t bw = 0;
+    for (int32_t k = g.ptr[i]; k < g.ptr[i + 1]; ++k) {
+      const int32_t c = rep[g.nbr[k]];
+      if (c != i && csize[c] < 4 && g.wgt[k] > bw) {
+        best = c;
+        bw = g.wgt[k];
+      }
+    }
+    if (best >= 0 && csize[i] == 1) {  // still alone (nobody joined it meanwhile)
+      rep[i] = best;
+      ++csize[best];
+      csize[i] = 0;
+    }
+  }
+  cid.assign(m, -1);
+  int32_t nc = 0;
+  for (int32_t i = 0; i < m; ++i)
+    if (rep[i] == i) cid[i] = nc++;  // clusters numbered by their smallest row: locality survives
+  for (int32_t i = 0; i < m; ++i) cid[i] = cid[rep[i]];
+  return nc;
+}
+
+WGraph coarsen_graph(const WGraph& g, const std::vector<int32_t>& cid, int32_t nc) {
+  struct E { uint64_t key; int64_t w; };
+  std::vector<E> es;
+  es.reserve(g.nbr.size());
+  for (int32_t i = 0; i < g.n(); ++i)
+    for (int32_t k = g.ptr[i]; k < g.ptr[i + 1]; ++k) {
+      const int32_t a = cid[i], b = cid[g.nbr[k]];
+      if (a != b) es.push_back({((uint64_t)(uint32_t)a << 32) | (uint32_t)b, g.wgt[k]});
+    }
+  std::sort(es.begin(), es.end(), [](const E& x, const E& y) { return x.key < y.key; });
+  WGraph c;
+  c.ptr.assign(nc + 1, 0);
+  uint64_t last = ~0ull;
+  for (const E& e : es) {
+    if (e.key == last) {
+      c.wgt.back() += e.w;
+    } else {
+      c.nbr.push_back((int32_t)(e.key & 0xffffffffu));
+      c.wgt.push_back(e.w);
+      ++c.ptr[(e.key >> 32) + 1];
+      last = e.key;
+    }
+  }
+  for (int32_t i = 0; i < nc; ++i) c.ptr[i + 1] += c.ptr[i];
+  return c;
+}
+
+}  // namespace
+
+bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* colidx0,
+                         std::vector<AmgLevelHost>& levels, std::string& why) {
+  levels.clear();
+  levels.emplace_back();
+  levels[0].nb = nb0;
+  levels[0].nnzb = rowptr0[nb0];
+  const int32_t* rowptr = rowptr0;
+  const int32_t* colidx = colidx0;
+  std::vector<int64_t> bw, bw_next;  // level-0 blocks behind each block of the current level
+  for (;;) {
+    AmgLevelHost& L = levels.back();
+    const int32_t nb = L.nb;
+    if (nb <= AMG_MAX_COARSEST) return levels.size() > 1 || (why = "system already tiny", false);
+    if ((int)levels.size() >= AMG_MAX_LEVELS) {
+      why = "too many levels";
+      return false;
+    }
+    // 3 matching passes: aggregates of up to 8 rows
+    WGraph g = graph_from_pattern(nb, rowptr, colidx, bw.empty() ? nullptr : bw.data());
+    std::vector<int32_t> agg(nb);
+    std::iota(agg.begin(), agg.end(), 0);
+    int32_t nc = nb;
+    for (int pass = 0; pass < 3 && nc > AMG_MAX_COARSEST / 2; ++pass) {
+      std::vector<int32_t> cid;
+      const int32_t m = match_pass(g, cid);
+      for (int32_t& a : agg) a = cid[a];
+      g = coarsen_graph(g, cid, m);
+      nc = m;
+    }
+    if (nc > nb - nb / 4) {  // matching stalls (isolated rows, stars): no useful hierarchy
+      why = "graph does not coarsen";
+      return false;
+    }
+    L.agg = agg;
+    L.mptr.assign(nc + 1, 0);
+    for (int32_t i = 0; i < nb; ++i) ++L.mptr[agg[i] + 1];
+    for (int32_t a = 0; a < nc; ++a) L.mptr[a + 1] += L.mptr[a];
+    L.mem.resize(nb);
+    {
+      std::vector<int32_t> fill(L.mptr.begin(), L.mptr.end() - 1);
+      for (int32_t i = 0; i < nb; ++i) L.mem[fill[agg[i]]++] = i;
+    }
+    // coarse pattern and the list of fine blocks behind every coarse block
+    struct Ent { int32_t I, J, k, i; };
+    std::vector<Ent> ents((size_t)L.nnzb);
+    for (int32_t i = 0; i < nb; ++i)
+      for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int32_t I = agg[i], J = agg[colidx[k]];
+        ents[(size_t)k] = {I, J == I ? -1 : J, k, i};  // -1: the diagonal sorts first
+      }
+    std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) {
+      if (x.I != y.I) return x.I < y.I;
+      if (x.J != y.J) return x.J < y.J;
+      return x.k < y.k;
+    });
+    AmgLevelHost C;
+    C.nb = nc;
+    C.rowptr.assign(nc + 1, 0);
+    L.gblk.resize(ents.size());
+    L.grow.resize(ents.size());
+    int32_t lastI = -1, lastJ = -2;
+    bw_next.clear();
+    for (size_t e = 0; e < ents.size(); ++e) {
+      const Ent& t = ents[e];
+      if (t.I != lastI || t.J != lastJ) {
+        C.colidx.push_back(t.J < 0 ? t.I : t.J);
+        bw_next.push_back(0);
+        L.gptr.push_back((int32_t)e);
+        ++C.rowptr[t.I + 1];
+        lastI = t.I;
+        lastJ = t.J;
+      }
+      L.gblk[e] = t.k;
+      L.grow[e] = t.i;
+      bw_next.back() += bw.empty() ? 1 : bw[(size_t)t.k];
+    }
+    L.gptr.push_back((int32_t)ents.size());
+    for (int32_t a = 0; a < nc; ++a) C.rowptr[a + 1] += C.rowptr[a];
+    C.nnzb = (int64_t)C.colidx.size();
+    levels.push_back(std::move(C));
+    bw.swap(bw_next);
+    rowptr = levels.back().rowptr.data();
+    colidx = levels.back().colidx.data();
+  }
+}
+
+}  // namespace sim3opt

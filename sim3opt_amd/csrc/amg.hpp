@@ -1,0 +1,41 @@
+// amg.hpp -- host-side set-up of the aggregation-multigrid preconditioner (structure only).
+//
+// The LM normal matrix of a pose graph, H = sum_e [J0 J1]^T W [J0 J1], is a connection Laplacian:
+// its low-energy modes are the fields dx_v = Ad(S_v) g, g in R^7 (a global right-multiplication
+// S_v -> S_v exp(g) leaves every residual log(C S_v0 S_v1^-1) unchanged; in the left perturbation
+// VertexSim3Expmap::oplusImpl uses, that is dx_v = Ad(S_v) g).  Block-Jacobi cannot see them, so on
+// locally connected graphs (Manhattan world: every vertex linked to ~20 neighbours a few cells
+// away) PCG needs thousands of iterations.  The hierarchy here coarsens the GRAPH by pairwise
+// matching (3 passes = aggregates of up to 8 block rows per level); the numbers (Galerkin products
+// with the Ad-transported piecewise-constant prolongation) are formed on the GPU after every
+// linearisation (engine.hip / amg_kernels.hpp).  The reference solves the system exactly
+// (LinearSolverEigen, kitti_surf.cpp:553-554); this is how the PCG gets to the same answer in tens
+// of iterations on config 3.  Pure host C++17, no GPU calls.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sim3opt {
+
+struct AmgLevelHost {
+  int32_t nb = 0;   // block rows of this level
+  int64_t nnzb = 0; // stored blocks of this level (level 0: the engine's own pattern)
+  std::vector<int32_t> rowptr, colidx;  // pattern (diagonal first, then unique sorted columns); empty on level 0
+  // transfer to the next (coarser) level; empty on the coarsest level
+  std::vector<int32_t> agg;        // nb: aggregate (= coarse block row) of each row
+  std::vector<int32_t> mptr, mem;  // coarse nb + 1, nb: rows of each aggregate, ascending
+  std::vector<int32_t> gptr;       // coarse nnzb + 1: contributions to each coarse block ...
+  std::vector<int32_t> gblk, grow; // ... as (block index, block row) of THIS level, ascending block index
+};
+
+constexpr int AMG_MAX_COARSEST = 64;  // block rows of the dense coarsest level (448 unknowns)
+constexpr int AMG_MAX_LEVELS = 10;
+
+// Builds the level patterns from the level-0 block-CSR pattern.  Returns false (with a reason)
+// when the graph does not coarsen to AMG_MAX_COARSEST rows, e.g. star-like graphs.
+bool build_amg_hierarchy(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
+                         std::vector<AmgLevelHost>& levels, std::string& why);
+
+}  // namespace sim3opt

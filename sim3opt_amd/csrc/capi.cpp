@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/sim3opt.h"
+#include "amg.hpp"
 #include "comm.hpp"
 #include "engine.hpp"
 #include "graph.hpp"
@@ -367,6 +368,26 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean) {
   if (!g || !ms_mean || reps < 1) return fail(g, SIM3OPT_ERR_ARG, "bench_spmv: bad argument");
   if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv: call sim3opt_initialize first");
   return engine_bench_spmv(g->engine, reps, ms_mean, g->err);
+}
+
+int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels, int32_t* rows,
+                          int64_t* blocks, int32_t* aggregate_of_row) {
+  if (!g || !n_levels || capacity < 0) return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: bad argument");
+  Structure st;
+  if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
+  std::vector<AmgLevelHost> levels;
+  std::string why;
+  if (!build_amg_hierarchy(st.nb, st.rowptr.data(), st.colidx.data(), levels, why)) {
+    g->err = "amg_hierarchy: " + why;
+    return SIM3OPT_ERR_STATE;
+  }
+  *n_levels = (int32_t)levels.size();
+  for (int32_t l = 0; l < *n_levels && l < capacity; ++l) {
+    if (rows) rows[l] = levels[l].nb;
+    if (blocks) blocks[l] = levels[l].nnzb;
+  }
+  if (aggregate_of_row) std::memcpy(aggregate_of_row, levels[0].agg.data(), sizeof(int32_t) * (size_t)st.nb);
+  return SIM3OPT_OK;
 }
 
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean) {

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "amg.hpp"
 #include "comm.hpp"
 #include "engine.hpp"
 
@@ -379,22 +380,38 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
 }
 
 // ------------------------------------------------------------------------------------------
-// block-Jacobi preconditioner: Minv = (H_ii + lambda I)^-1, one lane per block row
-// (Gauss-Jordan without pivoting; positive pivots <=> SPD block)
+// block-Jacobi preconditioner / smoother: Minv = omega (D + lambda W)^-1, one lane per block row
+// (Gauss-Jordan without pivoting; positive pivots <=> SPD block).  Level 0 of the system:
+// D = the row's diagonal block, W = I.  Coarse multigrid levels (diagH, W given): D = the undamped
+// Galerkin diagonal block, W = P^T P; the damped block is also stored back into vals.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __restrict__ rowptr,
-                                               const double* __restrict__ vals, double lambda,
-                                               double* __restrict__ Minv, DevScalars* sc) {
+                                               double* __restrict__ vals, double lambda,
+                                               double* __restrict__ Minv, DevScalars* sc,
+                                               double omega, const double* __restrict__ diagH,
+                                               const double* __restrict__ W) {
   const int row = r0 + blockIdx.x * WG + threadIdx.x;
   if (row >= r1) return;
   double a[7][7];
-  const double* src = vals + (size_t)49 * rowptr[row];
+  double* blk = vals + (size_t)49 * rowptr[row];
+  const double* src = diagH ? diagH + (size_t)49 * row : blk;
 #pragma unroll
   for (int c = 0; c < 7; ++c)
 #pragma unroll
     for (int r = 0; r < 7; ++r) a[r][c] = src[7 * c + r];
+  if (W) {
+    const double* w = W + (size_t)49 * row;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) a[i][i] += lambda;
+    for (int c = 0; c < 7; ++c)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        a[r][c] += lambda * w[7 * c + r];
+        blk[7 * c + r] = a[r][c];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a[i][i] += lambda;
+  }
   bool spd = true;
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
@@ -419,8 +436,10 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 #pragma unroll
   for (int r = 0; r < 7; ++r)
 #pragma unroll
-    for (int c = 0; c < 7; ++c) dst[7 * r + c] = a[r][c];
+    for (int c = 0; c < 7; ++c) dst[7 * r + c] = omega * a[r][c];
 }
+
+#include "amg_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
@@ -439,7 +458,10 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 //   * column indices / row ends: one coalesced vector load per 64, then v_readlane / ds_bpermute;
 //   * NT: the once-read block stream bypasses the cache policy so p stays in L2 / Infinity Cache;
 //   * a row ends with a wave-uniform branch (reduce 7 columns, add lambda p, store q, dots).
-template <int CH, bool NT>
+// MODE 0: q = A p (+ the dot partials; the PCG's SpMV).  The multigrid preconditioner reuses the
+// same stream for its two matrix passes per level: MODE 1: q = rvec - A p (residual),
+// MODE 2: q = p + Minv (rvec - A p) (one damped block-Jacobi step; Minv = omega D^-1, row-major).
+template <int CH, bool NT, int MODE>
 __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
@@ -449,13 +471,14 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
                                                   double* __restrict__ partials,
                                                   const double* __restrict__ rvec,
                                                   double* __restrict__ partials_r,
-                                                  DevScalars* __restrict__ sc) {
+                                                  DevScalars* __restrict__ sc,
+                                                  const double* __restrict__ Minv, int lam_sc) {
   __shared__ double sh[4];
   if (sc) {
     if (sc->done) return;
-    lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
+    if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
     // the previous update was the last allowed one: later launches become no-ops
-    if (blockIdx.x == 0 && threadIdx.x == 0 && sc->stop) sc->done = 1;
+    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0 && sc->stop) sc->done = 1;
   }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -465,6 +488,34 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
   const int rA = wrow[w], rB = wrow[w + 1];
   double pq = 0.0, pr = 0.0;
+  // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
+  auto row_end = [&](int row, double acc) {
+    double y = acc;
+#pragma unroll
+    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
+    double pi = 0.0, d = 0.0;
+    if (lane < 7) {
+      pi = p[(size_t)7 * row + lane];
+      y += lambda * pi;
+      if (MODE == 0) {
+        q[(size_t)7 * row + lane] = y;
+        pq += pi * y;
+        if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
+      } else {
+        d = rvec[(size_t)7 * row + lane] - y;
+        if (MODE == 1) q[(size_t)7 * row + lane] = d;
+      }
+    }
+    if (MODE == 2) {
+      double o = pi;
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const double dm = __shfl(d, m);
+        if (lane < 7) o += Minv[(size_t)49 * row + 7 * lane + m] * dm;
+      }
+      if (lane < 7) q[(size_t)7 * row + lane] = o;
+    }
+  };
   if (rA < rB) {
     const int kbeg = rowptr[rA], kend = rowptr[rB];
     // row ends of this span, 64 at a time, one per lane
@@ -514,16 +565,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
         const int kk = k + u;
         if (kk < kend) {
           if (kk == k1) {  // row `row` is complete
-            double y = acc;
-#pragma unroll
-            for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-            if (lane < 7) {
-              const double pi = p[(size_t)7 * row + lane];
-              y += lambda * pi;
-              q[(size_t)7 * row + lane] = y;
-              pq += pi * y;
-              if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
-            }
+            row_end(row, acc);
             acc = 0.0;
             ++row;
             if (row - rbase >= 64) {
@@ -539,19 +581,9 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
       for (int u = 0; u < CH; ++u) vc[u] = vn[u];
       xgc = xgn;
     }
-    {  // last row of the span
-      double y = acc;
-#pragma unroll
-      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-      if (lane < 7) {
-        const double pi = p[(size_t)7 * row + lane];
-        y += lambda * pi;
-        q[(size_t)7 * row + lane] = y;
-        pq += pi * y;
-        if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
-      }
-    }
+    row_end(row, acc);  // last row of the span
   }
+  if (MODE != 0) return;
   const double s = block_sum(pq, sh);
   if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
   if (rvec) {
@@ -746,7 +778,7 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
                                                  const double* __restrict__ part_d,
                                                  const double* __restrict__ part_g, int npart,
                                                  const double* __restrict__ Minv,
-                                                 double* __restrict__ z,
+                                                 const double* zin, double* zout,
                                                  const double* __restrict__ w,
                                                  double* __restrict__ p, double* __restrict__ sv,
                                                  double* __restrict__ x, double* __restrict__ r,
@@ -787,7 +819,7 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
     const size_t j = (size_t)7 * row + rr;
     double rv = 0.0;
     if (act) {
-      const double pn = z[j] + beta * p[j];
+      const double pn = zin[j] + beta * p[j];
       const double sn = w[j] + beta * sv[j];
       p[j] = pn;
       sv[j] = sn;
@@ -802,7 +834,7 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
         const double rc = __shfl(rv, base + cc);
         if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
       }
-      if (act) z[j] = zv;
+      if (act) zout[j] = zv;
     }
   }
   if (commit) {
@@ -928,9 +960,28 @@ class Engine {
   double* d_Gm = nullptr;
   bool use_chain = false;
   int chain_seg = 256;
-  // hipGraph of PCG_GRAPH_ITERS iterations (single GPU, untimed runs): replayed per chunk
+  // aggregation multigrid preconditioner (amg.hpp, amg_kernels.hpp); level 0 aliases the system
+  struct AmgLevel {
+    int32_t nb = 0;
+    int64_t nnzb = 0;
+    int32_t *rowptr = nullptr, *colidx = nullptr, *wrow = nullptr;
+    int span_grid = 0;
+    double *vals = nullptr, *diagH = nullptr, *W = nullptr, *Minv = nullptr;
+    int32_t *agg = nullptr, *mptr = nullptr, *mem = nullptr, *gptr = nullptr, *gblk = nullptr, *grow = nullptr;
+    double *r = nullptr, *x = nullptr, *t = nullptr;  // level right-hand side, iterate, residual / result
+  };
+  std::vector<AmgLevel> amg;
+  std::vector<void*> amg_owned;
+  double *d_P = nullptr, *d_Ainv = nullptr, *d_az = nullptr;
+  int32_t* d_row2v = nullptr;
+  bool use_amg = false, amg_stale = true;
+  double amg_omega = 0.8;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
+  int amg_visits[AMG_MAX_LEVELS + 1];  // cycles spent on level l per visit of level l-1 (1 = V, 2 = W)
+  bool amg_additive = false;           // level 0 additive: no fine-level matrix pass in the cycle
+  // hipGraph of `graph_iters` PCG iterations (single GPU, untimed runs): replayed per chunk
   hipGraphExec_t pcg_graph = nullptr;
-  bool pcg_graph_chain = false;
+  int pcg_graph_kind = -1;
+  int graph_iters = PCG_GRAPH_ITERS;
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
   bool linearized = false;
@@ -954,6 +1005,9 @@ class Engine {
                     d_sub_first, d_sub_cnt, d_Gm};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    for (void* p : amg_owned)
+      if (p) (void)hipFree(p);
+    amg_owned.clear();
     if (h_sc) (void)hipHostFree(h_sc);
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -1084,6 +1138,25 @@ class Engine {
       HIPCHK(hipMalloc((void**)v, sizeof(double) * n_alloc));
       HIPCHK(hipMemset(*v, 0, sizeof(double) * n_alloc));
     }
+    // multigrid for large loop-rich graphs (config 3: every vertex tied to ~20 neighbours), where
+    // block-Jacobi PCG needs thousands of iterations; same well-posedness condition as the chain
+    if (const char* ev = std::getenv("SIM3OPT_AMG_OMEGA")) amg_omega = std::max(0.1, std::min(0.95, std::atof(ev)));
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = 2;  // W-cycle (measured: DESIGN.md)
+    if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) {  // e.g. "122": visits of levels 1, 2, 3...
+      int last = 1;
+      for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
+        if ((int)std::strlen(ev) >= l && ev[l - 1] >= '1' && ev[l - 1] <= '3') last = ev[l - 1] - '0';
+        amg_visits[l] = last;
+      }
+    }
+    if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
+    const double avg_off = nb > 0 ? (double)(nnzb - nb) / nb : 0.0;
+    if (comm.world == 1 && !use_chain &&
+        (opt.preconditioner == 2 ||
+         (opt.preconditioner < 0 && opt.fix_small_angle_b != 0 && nb >= 20000 && avg_off >= 8.0))) {
+      int rc = amg_init(s, err);
+      if (rc) return rc;
+    }
     HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * MAX_GRID));
     HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * MAX_GRID));
     HIPCHK(hipMalloc((void**)&d_sc, sizeof(DevScalars)));
@@ -1146,6 +1219,206 @@ class Engine {
     return SIM3OPT_OK;
   }
 
+  // ---- aggregation multigrid ----
+  template <typename T>
+  int amg_up(T*& dptr, const std::vector<T>& h, std::string& err) {
+    HIPCHK(hipMalloc((void**)&dptr, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    amg_owned.push_back(dptr);
+    if (!h.empty()) HIPCHK(hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return SIM3OPT_OK;
+  }
+  int amg_alloc(double*& dptr, size_t count, std::string& err) {
+    HIPCHK(hipMalloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
+    amg_owned.push_back(dptr);
+    HIPCHK(hipMemset(dptr, 0, sizeof(double) * std::max<size_t>(count, 1)));
+    return SIM3OPT_OK;
+  }
+
+  // structure of the hierarchy (once per initialize); leaves use_amg false when the graph does
+  // not coarsen (block-Jacobi is used then)
+  int amg_init(const Structure& s, std::string& err) {
+    std::vector<AmgLevelHost> H;
+    std::string why;
+    if (!build_amg_hierarchy(nb, s.rowptr.data(), s.colidx.data(), H, why)) {
+      if (opt.verbose) std::fprintf(stderr, "sim3opt: no multigrid hierarchy (%s): block-Jacobi\n", why.c_str());
+      return SIM3OPT_OK;
+    }
+    const int nl = (int)H.size();
+    amg.assign(nl, AmgLevel());
+    int rc = SIM3OPT_OK;
+#define AMGCHK(call) do { rc = (call); if (rc) return rc; } while (0)
+    AmgLevel& L0 = amg[0];
+    L0.nb = nb; L0.nnzb = nnzb;
+    L0.rowptr = d_rowptr; L0.colidx = d_colidx; L0.wrow = d_wrow; L0.span_grid = span_grid;
+    L0.vals = d_vals; L0.Minv = d_Minv; L0.r = d_r; L0.x = d_z;
+    AMGCHK(amg_alloc(d_az, (size_t)n, err));
+    AMGCHK(amg_alloc(d_P, (size_t)49 * nb, err));
+    AMGCHK(amg_up(d_row2v, s.row2vertex, err));
+    L0.t = d_az;
+    for (int l = 0; l < nl; ++l) {
+      AmgLevel& L = amg[l];
+      const AmgLevelHost& h = H[l];
+      if (l > 0) {
+        L.nb = h.nb; L.nnzb = h.nnzb;
+        AMGCHK(amg_up(L.rowptr, h.rowptr, err));
+        AMGCHK(amg_up(L.colidx, h.colidx, err));
+        // coarse levels are latency-bound, not bandwidth-bound: one block row per wavefront
+        L.span_grid = std::max(1, (L.nb + 3) / 4);
+        std::vector<int32_t> wrow(L.span_grid * 4 + 1);
+        partition_rows(L.nb, h.rowptr.data(), L.span_grid * 4, wrow.data());
+        AMGCHK(amg_up(L.wrow, wrow, err));
+        AMGCHK(amg_alloc(L.vals, (size_t)49 * L.nnzb, err));
+        AMGCHK(amg_alloc(L.diagH, (size_t)49 * L.nb, err));
+        AMGCHK(amg_alloc(L.W, (size_t)49 * L.nb, err));
+        AMGCHK(amg_alloc(L.Minv, (size_t)49 * L.nb, err));
+        AMGCHK(amg_alloc(L.r, (size_t)7 * L.nb, err));
+        AMGCHK(amg_alloc(L.x, (size_t)7 * L.nb, err));
+        AMGCHK(amg_alloc(L.t, (size_t)7 * L.nb, err));
+      }
+      if (l + 1 < nl) {
+        AMGCHK(amg_up(L.agg, h.agg, err));
+        AMGCHK(amg_up(L.mptr, h.mptr, err));
+        AMGCHK(amg_up(L.mem, h.mem, err));
+        AMGCHK(amg_up(L.gptr, h.gptr, err));
+        AMGCHK(amg_up(L.gblk, h.gblk, err));
+        AMGCHK(amg_up(L.grow, h.grow, err));
+      }
+    }
+    const size_t nc = (size_t)7 * amg[nl - 1].nb;
+    AMGCHK(amg_alloc(d_Ainv, nc * nc, err));
+#undef AMGCHK
+    if (opt.verbose) {
+      std::fprintf(stderr, "sim3opt: multigrid levels (rows/blocks):");
+      for (const AmgLevel& L : amg) std::fprintf(stderr, " %d/%lld", L.nb, (long long)L.nnzb);
+      std::fprintf(stderr, "\n");
+    }
+    use_amg = true;
+    amg_stale = true;
+    return SIM3OPT_OK;
+  }
+
+  // numbers of the hierarchy: once per linearisation (P = Ad(S_v) at the linearisation point)
+  int amg_setup(std::string& err) {
+    const int nl = (int)amg.size();
+    hipLaunchKernelGGL(k_amg_adjoint, dim3(grid_for(nb, WG)), dim3(WG), 0, stream, nb, d_row2v,
+                       d_states, d_P);
+    for (int l = 0; l + 1 < nl; ++l) {
+      const AmgLevel& F = amg[l];
+      AmgLevel& Cc = amg[l + 1];
+      const int gg = (int)((Cc.nnzb + 3) / 4), gw = (Cc.nb + 3) / 4;
+      if (l == 0) {
+        hipLaunchKernelGGL((k_amg_galerkin<true>), dim3(gg), dim3(WG), 0, stream, (int)Cc.nnzb, F.gptr,
+                           F.gblk, F.grow, F.colidx, F.vals, d_P, Cc.vals);
+        hipLaunchKernelGGL((k_amg_wsum<true>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
+                           d_P, Cc.W);
+      } else {
+        hipLaunchKernelGGL((k_amg_galerkin<false>), dim3(gg), dim3(WG), 0, stream, (int)Cc.nnzb, F.gptr,
+                           F.gblk, F.grow, F.colidx, F.vals, (const double*)nullptr, Cc.vals);
+        hipLaunchKernelGGL((k_amg_wsum<false>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
+                           F.W, Cc.W);
+      }
+      hipLaunchKernelGGL(k_amg_copydiag, dim3(grid_for(49 * (int64_t)Cc.nb, WG)), dim3(WG), 0, stream,
+                         Cc.nb, Cc.rowptr, Cc.vals, Cc.diagH);
+    }
+    HIPCHK(hipGetLastError());
+    amg_stale = false;
+    return SIM3OPT_OK;
+  }
+
+  // per trial: damped diagonal blocks, smoother inverses, dense inverse of the coarsest level
+  void amg_prepare(double lambda) {
+    const int nl = (int)amg.size();
+    for (int l = 0; l < nl; ++l) {
+      const AmgLevel& L = amg[l];
+      hipLaunchKernelGGL(k_jacobi, dim3(std::max(1, (L.nb + WG - 1) / WG)), dim3(WG), 0, stream, 0, L.nb,
+                         L.rowptr, L.vals, lambda, L.Minv, d_sc, l == 0 && amg_additive ? 1.0 : amg_omega,
+                         L.diagH, L.W);
+    }
+    const AmgLevel& Lc = amg[nl - 1];
+    hipLaunchKernelGGL(k_amg_dense_invert, dim3(1), dim3(AMG_DENSE_WG), 0, stream, Lc.nb, Lc.rowptr,
+                       Lc.colidx, Lc.vals, d_Ainv, d_sc);
+  }
+
+  void spmv_mode(const AmgLevel& L, int mode, int level, const double* v, double* out,
+                 const double* rvec) {
+    // level 0 carries the damping as a scalar (read from DevScalars: capturable); coarse levels
+    // have it inside their diagonal blocks.  Level 0 streams once (non-temporal), the rest is small.
+#define AMG_SPMV(NTV, MODEV)                                                                     \
+  hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
+                     L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, (double*)nullptr, rvec,     \
+                     (double*)nullptr, d_sc, L.Minv, level == 0 ? 1 : 0)
+    if (level == 0) { if (mode == 1) AMG_SPMV(true, 1); else AMG_SPMV(true, 2); }
+    else { if (mode == 1) AMG_SPMV(false, 1); else AMG_SPMV(false, 2); }
+#undef AMG_SPMV
+  }
+
+  void amg_restrict(int l, const double* t) {  // r_{l+1} = P^T t, x_{l+1} = Minv r_{l+1}
+    const AmgLevel& F = amg[l];
+    const AmgLevel& Cc = amg[l + 1];
+    const int gr = grid_for((Cc.nb + 8) / 9, 4);
+    const double* Minv_c = l + 2 < (int)amg.size() ? Cc.Minv : nullptr;  // coarsest: solved exactly
+    if (l == 0)
+      hipLaunchKernelGGL((k_amg_restrict<true>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
+                         d_P, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)d_sc);
+    else
+      hipLaunchKernelGGL((k_amg_restrict<false>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
+                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)d_sc);
+  }
+  void amg_prolong(int l, const double* xc, const double* xin, double* xout) {
+    const AmgLevel& F = amg[l];
+    const int gp = grid_for((F.nb + 8) / 9, 4);
+    if (l == 0)
+      hipLaunchKernelGGL((k_amg_prolong<true>), dim3(gp), dim3(WG), 0, stream, F.nb, F.agg, d_P, xc,
+                         xin, xout, (const DevScalars*)d_sc);
+    else
+      hipLaunchKernelGGL((k_amg_prolong<false>), dim3(gp), dim3(WG), 0, stream, F.nb, F.agg,
+                         (const double*)nullptr, xc, xin, xout, (const DevScalars*)d_sc);
+  }
+
+  // Solves the level-(l+1) problem approximately (right-hand side amg[l+1].r, first iterate
+  // amg[l+1].x = Minv r already there) by amg_visits[l+1] cycles; returns the buffer with the result.
+  const double* amg_coarse(int l) {
+    const int nl = (int)amg.size();
+    const AmgLevel& Cc = amg[l + 1];
+    if (l + 2 == nl) {
+      hipLaunchKernelGGL(k_amg_dense_apply, dim3(1), dim3(512), 0, stream, 7 * Cc.nb, d_Ainv, Cc.r,
+                         Cc.x, (const DevScalars*)d_sc);
+      return Cc.x;
+    }
+    double* res = amg_cycle(l + 1, Cc.x, Cc.t);
+    for (int g = 1; g < amg_visits[l + 1]; ++g) {  // W-cycle: again, from the current iterate
+      double* oth = res == Cc.x ? Cc.t : Cc.x;
+      spmv_mode(Cc, 2, l + 1, res, oth, Cc.r);  // pre-smoothing step
+      res = amg_cycle(l + 1, oth, res);
+    }
+    return res;
+  }
+
+  // One multigrid cycle on level l from the iterate `cur`; `other` is scratch; returns the buffer
+  // that holds the new iterate (always `other`):
+  //   t = r - A cur;  coarse correction;  cur += P x_c;  other = cur + Minv (r - A cur)
+  double* amg_cycle(int l, double* cur, double* other) {
+    const AmgLevel& F = amg[l];
+    spmv_mode(F, 1, l, cur, other, F.r);
+    amg_restrict(l, other);
+    const double* xc = amg_coarse(l);
+    amg_prolong(l, xc, cur, cur);
+    spmv_mode(F, 2, l, cur, other, F.r);
+    return other;
+  }
+
+  // d_az = M^-1 d_r; on entry d_z = Minv_0 d_r (written by the PCG step).  Multiplicative: one
+  // V(1,1) (or W) cycle from that iterate.  Additive on level 0 (no fine-level matrix pass in the
+  // preconditioner): M^-1 = D^-1 + P (coarse cycle) P^T.
+  void amg_apply() {
+    if (amg_additive) {
+      amg_restrict(0, d_r);
+      amg_prolong(0, amg_coarse(0), d_z, d_az);
+    } else {
+      amg_cycle(0, d_z, d_az);
+    }
+  }
+
   // ---- building blocks ----
   int chi2(double* out, std::string& err) {
     const int g = grid_for(e_hi - e_lo, WG);
@@ -1188,6 +1461,7 @@ class Engine {
       if (rc) return rc;
     }
     linearized = true;
+    amg_stale = true;
     kt.n_linearize += 1;
     return SIM3OPT_OK;
   }
@@ -1205,12 +1479,13 @@ class Engine {
                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const int g = spmv_grid();
 #define SPAN_CASE(CH, NTV)                                                                       \
-  hipExtLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb,   \
-                        d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,        \
-                        d_part_b, scp)
+  hipExtLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb, \
+                        d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,         \
+                        d_part_b, scp, (const double*)nullptr, 1)
 #define SPAN_PLAIN(CH, NTV)                                                                     \
-  hipLaunchKernelGGL((k_spmv_span<CH, NTV>), dim3(g), dim3(WG), 0, stream, nb, d_wrow, d_rowptr, \
-                     d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp)
+  hipLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, nb, d_wrow,       \
+                     d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp,     \
+                     (const double*)nullptr, 1)
     if (!ev0) {  // plain launch: capturable into a hipGraph
       if (spmv_chunk <= 4) { if (spmv_nt) SPAN_PLAIN(4, true); else SPAN_PLAIN(4, false); }
       else { if (spmv_nt) SPAN_PLAIN(8, true); else SPAN_PLAIN(8, false); }
@@ -1222,13 +1497,13 @@ class Engine {
 #undef SPAN_CASE
   }
 
-  int spmv_launch(double lambda, std::string& err) {  // the PCG's SpMV: w = A z, w.z, r.z
+  int spmv_launch(double lambda, const double* z, std::string& err) {  // the PCG's SpMV: w = A z, w.z, r.z
     hipEvent_t a = nullptr, b = nullptr;
     if (opt.time_kernels) {
       int rc = pool_get(a, b, err);
       if (rc) return rc;
     }
-    spmv_raw(lambda, d_z, d_q, d_r, d_sc, a, b);
+    spmv_raw(lambda, z, d_q, d_r, d_sc, a, b);
     return SIM3OPT_OK;
   }
 
@@ -1236,18 +1511,22 @@ class Engine {
   // result stays in d_x.  Two launches and one reduction point per iteration; the host only polls
   // a 100-byte struct every `pcg_check_every` iterations.
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
-    if (use_chain) {
-      // the block-tridiagonal factorisation can meet a non-positive pivot when H is numerically
-      // semi-definite (cond ~1e12 in the reference's as-written arithmetic): retry with block-Jacobi
-      bool chain_broke = false;
-      int rc = pcg_attempt(lambda, true, iters, rel_res, ok, &chain_broke, err);
-      if (rc || !chain_broke) return rc;
+    if (use_amg || use_chain) {
+      // the block-tridiagonal factorisation (or the multigrid's coarsest-level inverse) can meet a
+      // non-positive pivot when H is numerically semi-definite (cond ~1e12 in the reference's
+      // as-written arithmetic): retry with block-Jacobi
+      bool broke = false;
+      int rc = pcg_attempt(lambda, use_amg ? 2 : 1, iters, rel_res, ok, &broke, err);
+      if (rc || !broke) return rc;
     }
-    return pcg_attempt(lambda, false, iters, rel_res, ok, nullptr, err);
+    return pcg_attempt(lambda, 0, iters, rel_res, ok, nullptr, err);
   }
 
-  int pcg_attempt(double lambda, bool use_chain, int32_t* iters, double* rel_res, bool* ok,
+  // prec: 0 block-Jacobi, 1 chain segments, 2 aggregation multigrid
+  int pcg_attempt(double lambda, int prec, int32_t* iters, double* rel_res, bool* ok,
                   bool* chain_broke, std::string& err) {
+    const bool use_chain = prec == 1, use_mg = prec == 2;
+    double* const zin = use_mg ? d_az : d_z;  // preconditioned residual the PCG consumes
     const int nloc = r1 - r0;
     const int gj = std::max(1, (nloc + WG - 1) / WG);
     const int gv = grid_for((nloc + 8) / 9, 4);  // 36 block rows per workgroup pass
@@ -1273,27 +1552,40 @@ class Engine {
     HIPCHK(hipMemcpyAsync(&d_sc->iter, &h_sc->iter, offsetof(DevScalars, tmp_pq) - offsetof(DevScalars, iter),
                           hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(&d_sc->lambda, &h_sc->lambda, sizeof(double), hipMemcpyHostToDevice, stream));
-    if (use_chain)
+    if (use_mg) {
+      if (amg_stale) {
+        rc = amg_setup(err);
+        if (rc) return rc;
+      }
+      amg_prepare(lambda);
+    } else if (use_chain) {
       hipLaunchKernelGGL(k_chain_factor, dim3(std::max(1, (nseg + 63) / 64)), dim3(64), 0, stream,
                          r0, r1, chain_seg, d_rowptr, d_vals, d_sub_first, d_sub_cnt, lambda,
                          d_Minv, d_Gm, d_sc);
-    else
+    } else {
       hipLaunchKernelGGL(k_jacobi, dim3(gj), dim3(WG), 0, stream, r0, r1, d_rowptr, d_vals, lambda,
-                         d_Minv, d_sc);
+                         d_Minv, d_sc, 1.0, (const double*)nullptr, (const double*)nullptr);
+    }
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x, d_r,
                        d_z, d_p, d_s);
-    if (use_chain) {
+    if (use_chain || use_mg) {
       rc = fetch_scalars(err);  // did the factorisation succeed?
       if (rc) return rc;
       if (h_sc->fail) {
+        if (opt.verbose)
+          std::fprintf(stderr, "sim3opt: %s set-up met a non-positive pivot (lambda %.3g): block-Jacobi for this solve\n",
+                       use_mg ? "multigrid" : "chain", lambda);
         if (chain_broke) *chain_broke = true;
         *ok = false;
         *iters = 0;
         *rel_res = 0.0;
         return SIM3OPT_OK;
       }
-      hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
-                         d_Gm, d_r, d_z, (const DevScalars*)nullptr);
+      if (use_chain)
+        hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
+                           d_Gm, d_r, d_z, (const DevScalars*)nullptr);
+      else
+        amg_apply();
     }
     HIPCHK(hipGetLastError());
     if (multi) {
@@ -1307,23 +1599,27 @@ class Engine {
     // iteration stays eager (it carries it == 0); captured steps read the counter, the damping and
     // the stopping state from DevScalars, so one instantiated graph serves every solve.
     const bool graphed = !multi && !opt.time_kernels && opt.pcg_graph && max_it > PCG_GRAPH_ITERS;
-    if (graphed && (!pcg_graph || pcg_graph_chain != use_chain)) {
+    if (graphed && (!pcg_graph || pcg_graph_kind != prec)) {
       if (pcg_graph) { (void)hipGraphExecDestroy(pcg_graph); pcg_graph = nullptr; }
+      // a multigrid iteration is ~20 launches: shorter graphs waste fewer no-op launches after
+      // convergence
+      graph_iters = use_mg ? 4 : PCG_GRAPH_ITERS;
       hipGraph_t gr = nullptr;
       HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      for (int c = 0; c < PCG_GRAPH_ITERS; ++c) {
-        spmv_raw(lambda, d_z, d_q, d_r, d_sc);
+      for (int c = 0; c < graph_iters; ++c) {
+        spmv_raw(lambda, zin, d_q, d_r, d_sc);
         hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(WG), 0, stream, r0, r1, (1 + c) & 1, -1,
-                           (const double*)nullptr, d_part_a, d_part_b, gs, Minv_arg, d_z, d_q, d_p,
-                           d_s, d_x, d_r, d_sc);
+                           (const double*)nullptr, d_part_a, d_part_b, gs, Minv_arg,
+                           (const double*)zin, d_z, d_q, d_p, d_s, d_x, d_r, d_sc);
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
                              d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
+        if (use_mg) amg_apply();
       }
       HIPCHK(hipStreamEndCapture(stream, &gr));
       HIPCHK(hipGraphInstantiate(&pcg_graph, gr, nullptr, nullptr, 0));
       (void)hipGraphDestroy(gr);
-      pcg_graph_chain = use_chain;
+      pcg_graph_kind = prec;
     }
     for (;;) {
       rc = fetch_scalars(err);
@@ -1333,17 +1629,17 @@ class Engine {
         if (rc) return rc;
       }
       if (h_sc->done || h_sc->stop || h_sc->fail || it >= max_it) break;
-      if (graphed && it > 0 && par == 1 && max_it - it >= PCG_GRAPH_ITERS) {
+      if (graphed && it > 0 && par == 1 && max_it - it >= graph_iters) {
         // steps past max_iter cannot happen: the step that reaches it raises `stop`, and the
         // following launches of the replay are no-ops
-        const int reps = std::max(1, std::min(chunk, max_it - it) / PCG_GRAPH_ITERS);
+        const int reps = std::max(1, std::min(chunk, max_it - it) / graph_iters);
         for (int k = 0; k < reps; ++k) HIPCHK(hipGraphLaunch(pcg_graph, stream));
-        it += reps * PCG_GRAPH_ITERS;
+        it += reps * graph_iters;
         continue;
       }
       const int todo = graphed && it == 0 ? 1 : std::min(chunk, max_it - it);
       for (int c = 0; c < todo; ++c) {
-        rc = spmv_launch(lambda, err);
+        rc = spmv_launch(lambda, zin, err);
         if (rc) return rc;
         if (multi) {  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent), one 2-double all-reduce
           hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
@@ -1352,10 +1648,12 @@ class Engine {
           if (rc) return rc;
         }
         hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(WG), 0, stream, r0, r1, par, it, scal,
-                           d_part_a, d_part_b, gs, Minv_arg, d_z, d_q, d_p, d_s, d_x, d_r, d_sc);
+                           d_part_a, d_part_b, gs, Minv_arg, (const double*)zin, d_z, d_q, d_p, d_s,
+                           d_x, d_r, d_sc);
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
                              d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
+        if (use_mg) amg_apply();
         if (multi) {  // the next SpMV gathers z from every rank
           rc = comm.allgatherv(d_z, offs, stream, err);
           if (rc) return rc;

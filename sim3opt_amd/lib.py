@@ -103,6 +103,7 @@ SYMBOLS = {
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
@@ -387,6 +388,17 @@ class Graph:
         self._chk(self._L.sim3opt_solve(self._g, float(lam), _p(x, _dp), C.byref(it),
                                         C.byref(rr)))
         return x, it.value, rr.value
+
+    def amg_hierarchy(self):
+        """(rows per level, blocks per level, level-1 row of every level-0 block row); host only."""
+        nl = C.c_int32()
+        rows = np.zeros(16, dtype=np.int32)
+        blocks = np.zeros(16, dtype=np.int64)
+        nfree = self.num_vertices
+        agg = np.full(nfree, -1, dtype=np.int32)
+        self._chk(self._L.sim3opt_amg_hierarchy(self._g, 16, C.byref(nl), _p(rows, _ip),
+                                                blocks.ctypes.data_as(C.c_void_p), _p(agg, _ip)))
+        return rows[:nl.value].copy(), blocks[:nl.value].copy(), agg
 
     def bench_spmv(self, reps=20):
         ms = C.c_double()

@@ -188,3 +188,45 @@ def test_umeyama_alignment_and_kitti_original_map_rmse():
     assert abs(rm - 130.236) < 1e-2 and abs(mx - 264.069) < 1e-2  # un-optimised VO map vs GT
     with pytest.raises(L.Sim3OptError):
         L.align_trajectory(np.zeros((2, 3)), np.zeros((2, 3)))
+
+
+def test_amg_hierarchy_structure():
+    """Host set-up of the multigrid preconditioner (amg.cpp): pairwise matching coarsens a
+    Manhattan graph by ~8x per level down to <= 64 rows; aggregates are connected subsets of 8 block
+    rows (a few larger ones where left-over rows joined a neighbour); a star graph (nothing to match after the hub) is refused."""
+    from sim3opt_amd import synth
+    g = synth.manhattan(3000, 30000, dims=(17, 17, 10))
+    G = L.Graph()
+    G.add_vertices(g["states"], g["fixed"])
+    G.add_edges(g["v0"], g["v1"], g["meas"])
+    rows, blocks, agg = G.amg_hierarchy()
+    assert rows[0] == 2999 and blocks[0] == 2999 + 2 * 30000 - 2 * int(((g["v0"] == 0) | (g["v1"] == 0)).sum())
+    assert len(rows) >= 3 and rows[-1] <= 64
+    assert all(rows[l + 1] <= rows[l] // 3 for l in range(len(rows) - 2))  # 3 matching passes per level
+    assert all(blocks[l + 1] < blocks[l] for l in range(len(rows) - 1))
+    agg = agg[:2999]
+    assert agg.min() == 0 and agg.max() == rows[1] - 1
+    sizes = np.bincount(agg)
+    assert sizes.max() <= 64 and sizes.min() >= 1 and np.median(sizes) == 8
+    # every aggregate is connected in the graph (matching only ever merges neighbours)
+    free_of = np.cumsum(g["fixed"] == 0) - 1
+    a, b = free_of[g["v0"]], free_of[g["v1"]]
+    ok = (g["fixed"][g["v0"]] == 0) & (g["fixed"][g["v1"]] == 0)
+    a, b = a[ok], b[ok]
+    same = agg[a] == agg[b]
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    A = sp.coo_matrix((np.ones(same.sum()), (a[same], b[same])), shape=(2999, 2999))
+    ncomp, _ = csg.connected_components(A, directed=False)
+    assert ncomp == rows[1]
+    # deterministic
+    rows2, blocks2, agg2 = G.amg_hierarchy()
+    assert np.array_equal(rows, rows2) and np.array_equal(agg[:2999], agg2[:2999])
+    # star: vertex 1 tied to everyone, nothing else -> after the first pair nothing matches
+    S = L.Graph()
+    n = 400
+    S.add_vertices(np.tile(I8, (n, 1)), [1] + [0] * (n - 1))
+    S.add_edges(np.full(n - 2, 1), np.arange(2, n), np.tile(I8, (n - 2, 1)))
+    with pytest.raises(L.Sim3OptError) as ei:
+        S.amg_hierarchy()
+    assert ei.value.code == L.ERR_STATE
