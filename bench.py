@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one Levenberg-Marquardt iteration (chi2, per-edge residual + numeric Jacobians,
-block-CSR assembly, block-Jacobi PCG solve, oplus update, chi2 again, lambda policy) on
+block-CSR assembly, preconditioned CG solve, oplus update, chi2 again, lambda policy) on
 BASELINE.json configs[2]: the synthetic Manhattan-grid Sim(3) graph, 100k vertices / 1M edges,
 inputs resident in HBM before the timed region.  N > 1: the same graph, block rows partitioned
 across the ranks (strong scaling), RCCL all-gather of the PCG direction + fused scalar all-reduce.
@@ -42,6 +42,14 @@ def parse():
                          "0 = reference arithmetic as written (sim3_rv.h:166): LM stalls at "
                          "lambda ~1e8, reported separately as reference_arithmetic")
     ap.add_argument("--pcg-rel-tol", type=float, default=1e-8)
+    ap.add_argument("--preconditioner", type=int, default=-1,
+                    help="-1 automatic (multigrid on this workload at 1 GPU), 0 block-Jacobi, 2 multigrid")
+    ap.add_argument("--time-kernels", type=int, default=1,
+                    help="1: HIP-event pair around every SpMV launch of the PCG (roofline figure; "
+                         "disables hipGraph replay), 0: untimed launches")
+    ap.add_argument("--main-only", action="store_true",
+                    help="skip the comparison legs (block-Jacobi PCG, reference arithmetic): the run "
+                         "rocprofv3 profiles, so its per-kernel averages are those of the timed path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
                     help="multi-rank collectives: rccl (default; ncclAllReduce / grouped ncclBroadcast "
@@ -117,8 +125,8 @@ def main():
     # ---- workload (identical on every rank: same seeds) ----
     synth.DRIFT_TARGET = 0.05
     g = synth.manhattan(args.vertices, args.edges)
-    G = L.Graph(device=local_rank, time_kernels=1, pcg_rel_tol=args.pcg_rel_tol,
-                fix_small_angle_b=args.fix_small_angle_b)
+    G = L.Graph(device=local_rank, time_kernels=args.time_kernels, pcg_rel_tol=args.pcg_rel_tol,
+                fix_small_angle_b=args.fix_small_angle_b, preconditioner=args.preconditioner)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     transport_used = None
@@ -219,6 +227,8 @@ def main():
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         except Exception:
             traffic = None
+        prec_name = {0: "block-Jacobi", 1: "chain-segment", 2: "aggregation-multigrid (W-cycle)"}[
+            G.preconditioner_in_use()]
         roof = None
         if kt.n_spmv > 0:
             avg_ms = kt.ms_spmv / kt.n_spmv
@@ -234,22 +244,50 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: synthetic Manhattan-grid Sim3 pose graph "
                                    f"{args.vertices} vertices / {args.edges} edges, information I7, "
-                                   "vertex 0 fixed, numeric Jacobians delta=1e-9, block-Jacobi PCG "
+                                   f"vertex 0 fixed, numeric Jacobians delta=1e-9, {prec_name} PCG "
                                    f"rel tol {args.pcg_rel_tol:g}",
                        "vertices": args.vertices, "edges": args.edges,
                        "fix_small_angle_b": args.fix_small_angle_b,
+                       "preconditioner": prec_name,
                        "parallelism": "single GPU" if world == 1 else f"row-partition x{world}",
                        "transport": transport_used},
             "edges_iters_per_s": args.edges * K / dt,
             "chi2_initial": chi2_0, "chi2_final": chi2_final,
             "lm_trials": [int(s.trials) for s in stats],
             "pcg_iters": [int(s.pcg_iters) for s in stats],
+            "pcg_rel_res": [float("%.2e" % s.pcg_rel_res) for s in stats],
             "ms_linearize_mean": float(np.mean([s.ms_linearize for s in stats])),
             "ms_solve_mean": float(np.mean([s.ms_solve for s in stats])),
             "ms_update_mean": float(np.mean([s.ms_update for s in stats])),
             "roofline": roof,
         }
-        if world == 1 and args.fix_small_angle_b == 1:
+        if world == 1 and G.preconditioner_in_use() != 0 and not args.main_only:
+            # same K steps with plain block-Jacobi PCG, for comparison (not part of `value`)
+            J = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, preconditioner=0,
+                        fix_small_angle_b=args.fix_small_angle_b)
+            J.add_vertices(g["states"], g["fixed"])
+            J.add_edges(g["v0"], g["v1"], g["meas"])
+            J.initialize()
+            if args.warmup > 0:
+                J.optimize(args.warmup)
+            torch.cuda.synchronize()
+            tj0 = time.perf_counter()
+            jdone, jstats = 0, []
+            while jdone < K:
+                it = J._L.sim3opt_optimize(J._g, K - jdone)
+                if it <= 0:
+                    break
+                jdone += it
+                jstats += J.stats()
+            torch.cuda.synchronize()
+            jdt = time.perf_counter() - tj0
+            out["block_jacobi_pcg"] = {
+                "steps": jdone, "value": jdone / jdt, "unit": "LM iter/s", "chi2_final": J.chi2(),
+                "pcg_iters": [int(s.pcg_iters) for s in jstats],
+                "pcg_rel_res": [float("%.2e" % s.pcg_rel_res) for s in jstats],
+                "note": "preconditioner = 0: solves stop at the 1000-iteration cap (truncated steps)"}
+            J.close()
+        if world == 1 and args.fix_small_angle_b == 1 and not args.main_only:
             # same K steps in the reference's as-written arithmetic (not part of `value`)
             R = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, fix_small_angle_b=0)
             R.add_vertices(g["states"], g["fixed"])

@@ -179,6 +179,9 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
 /* HBM read calibration over the same value array (bench only): mode 0 = 16 B/lane contiguous,
  * 1 = 8 B/lane contiguous, 2 = 8 B/lane on 49 of 64 lanes per 392-B block (the SpMV's shape) */
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
+/* Preconditioner the PCG of this (initialized) graph uses: 0 block-Jacobi, 1 chain segments,
+ * 2 aggregation multigrid (what `preconditioner = -1` resolved to); negative = error code. */
+int sim3opt_preconditioner_in_use(const sim3opt_graph* g);
 /* Structure of the multigrid hierarchy `preconditioner = 2` would use for this graph (host only, no
  * GPU needed, may be called before initialize): *n_levels levels; rows[l] / blocks[l] = block rows
  * and stored 7x7 blocks of level l (up to `capacity` levels are written); aggregate_of_row (may be

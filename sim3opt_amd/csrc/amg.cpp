@@ -2,6 +2,8 @@
 #include "amg.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 namespace sim3opt {
@@ -144,7 +146,12 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
     std::vector<int32_t> agg(nb);
     std::iota(agg.begin(), agg.end(), 0);
     int32_t nc = nb;
-    for (int pass = 0; pass < 3 && nc > AMG_MAX_COARSEST / 2; ++pass) {
+    int npass = 3;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_PASSES")) {  // tuning knob: passes per level, e.g. "344"
+      const size_t l = std::min(levels.size() - 1, std::strlen(ev) - 1);
+      if (std::strlen(ev) > 0 && ev[l] >= '1' && ev[l] <= '6') npass = ev[l] - '0';
+    }
+    for (int pass = 0; pass < npass && nc > AMG_MAX_COARSEST / 2; ++pass) {
       std::vector<int32_t> cid;
       const int32_t m = match_pass(g, cid);
       for (int32_t& a : agg) a = cid[a];

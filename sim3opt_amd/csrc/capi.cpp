@@ -370,6 +370,12 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean) {
   return engine_bench_spmv(g->engine, reps, ms_mean, g->err);
 }
 
+int sim3opt_preconditioner_in_use(const sim3opt_graph* g) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return SIM3OPT_ERR_STATE;
+  return engine_preconditioner(g->engine);
+}
+
 int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels, int32_t* rows,
                           int64_t* blocks, int32_t* aggregate_of_row) {
   if (!g || !n_levels || capacity < 0) return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: bad argument");

@@ -488,32 +488,38 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
   const int rA = wrow[w], rB = wrow[w + 1];
   double pq = 0.0, pr = 0.0;
+  // per-row operands are requested when the row starts and consumed when it ends
+  double pi_n = 0.0, rv_n = 0.0, mv = 0.0;
+  auto row_begin = [&](int row) {
+    pi_n = p[(size_t)7 * row + r];
+    if (rvec) rv_n = rvec[(size_t)7 * row + r];
+    if (MODE == 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
+  };
   // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
+  // (row sums are valid in lanes 0..6)
   auto row_end = [&](int row, double acc) {
     double y = acc;
 #pragma unroll
     for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-    double pi = 0.0, d = 0.0;
-    if (lane < 7) {
-      pi = p[(size_t)7 * row + lane];
-      y += lambda * pi;
-      if (MODE == 0) {
+    const double pi = pi_n;
+    y += lambda * pi;
+    if (MODE == 0) {
+      if (lane < 7) {
         q[(size_t)7 * row + lane] = y;
         pq += pi * y;
-        if (rvec) pr += rvec[(size_t)7 * row + lane] * pi;
+        if (rvec) pr += rv_n * pi;
+      }
+    } else {
+      const double d = rv_n - y;
+      if (MODE == 1) {
+        if (lane < 7) q[(size_t)7 * row + lane] = d;
       } else {
-        d = rvec[(size_t)7 * row + lane] - y;
-        if (MODE == 1) q[(size_t)7 * row + lane] = d;
-      }
-    }
-    if (MODE == 2) {
-      double o = pi;
+        const double pr_ = mv * __shfl(d, c49);  // Minv(r, c) d_c
+        double o = pr_;
 #pragma unroll
-      for (int m = 0; m < 7; ++m) {
-        const double dm = __shfl(d, m);
-        if (lane < 7) o += Minv[(size_t)49 * row + 7 * lane + m] * dm;
+        for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
+        if (lane < 7) q[(size_t)7 * row + lane] = pi + o;
       }
-      if (lane < 7) q[(size_t)7 * row + lane] = o;
     }
   };
   if (rA < rB) {
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
     int rbase = rA;
     int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
     int row = rA;
+    row_begin(row);
     int k1 = __builtin_amdgcn_readlane(rpv, 0);
     // column indices, 64 blocks at a time, one per lane; window w covers [kbeg + 64 w, +64)
     int cbase = kbeg;
@@ -568,6 +575,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
             row_end(row, acc);
             acc = 0.0;
             ++row;
+            row_begin(row);
             if (row - rbase >= 64) {
               rbase += 64;
               rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
@@ -975,7 +983,7 @@ class Engine {
   double *d_P = nullptr, *d_Ainv = nullptr, *d_az = nullptr;
   int32_t* d_row2v = nullptr;
   bool use_amg = false, amg_stale = true;
-  double amg_omega = 0.8;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
+  double amg_omega = 0.9;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
   int amg_visits[AMG_MAX_LEVELS + 1];  // cycles spent on level l per visit of level l-1 (1 = V, 2 = W)
   bool amg_additive = false;           // level 0 additive: no fine-level matrix pass in the cycle
   // hipGraph of `graph_iters` PCG iterations (single GPU, untimed runs): replayed per chunk
@@ -1343,10 +1351,12 @@ class Engine {
                  const double* rvec) {
     // level 0 carries the damping as a scalar (read from DevScalars: capturable); coarse levels
     // have it inside their diagonal blocks.  Level 0 streams once (non-temporal), the rest is small.
+    // Only level-0 launches test the `done` flag: on the latency-bound coarse levels that dependent
+    // scalar load in front of the kernel costs more than the few idle launches after convergence.
 #define AMG_SPMV(NTV, MODEV)                                                                     \
   hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
                      L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, (double*)nullptr, rvec,     \
-                     (double*)nullptr, d_sc, L.Minv, level == 0 ? 1 : 0)
+                     (double*)nullptr, level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1)
     if (level == 0) { if (mode == 1) AMG_SPMV(true, 1); else AMG_SPMV(true, 2); }
     else { if (mode == 1) AMG_SPMV(false, 1); else AMG_SPMV(false, 2); }
 #undef AMG_SPMV
@@ -1362,7 +1372,7 @@ class Engine {
                          d_P, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)d_sc);
     else
       hipLaunchKernelGGL((k_amg_restrict<false>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
-                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)d_sc);
+                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)nullptr);
   }
   void amg_prolong(int l, const double* xc, const double* xin, double* xout) {
     const AmgLevel& F = amg[l];
@@ -1372,7 +1382,7 @@ class Engine {
                          xin, xout, (const DevScalars*)d_sc);
     else
       hipLaunchKernelGGL((k_amg_prolong<false>), dim3(gp), dim3(WG), 0, stream, F.nb, F.agg,
-                         (const double*)nullptr, xc, xin, xout, (const DevScalars*)d_sc);
+                         (const double*)nullptr, xc, xin, xout, (const DevScalars*)nullptr);
   }
 
   // Solves the level-(l+1) problem approximately (right-hand side amg[l+1].r, first iterate
@@ -1382,7 +1392,7 @@ class Engine {
     const AmgLevel& Cc = amg[l + 1];
     if (l + 2 == nl) {
       hipLaunchKernelGGL(k_amg_dense_apply, dim3(1), dim3(512), 0, stream, 7 * Cc.nb, d_Ainv, Cc.r,
-                         Cc.x, (const DevScalars*)d_sc);
+                         Cc.x, (const DevScalars*)nullptr);
       return Cc.x;
     }
     double* res = amg_cycle(l + 1, Cc.x, Cc.t);
@@ -1934,6 +1944,8 @@ void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end) {
   if (begin) *begin = e->r0;
   if (end) *end = e->r1;
 }
+
+int engine_preconditioner(const Engine* e) { return e->use_amg ? 2 : (e->use_chain ? 1 : 0); }
 
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {
   if (out) *out = e->kt;

@@ -103,6 +103,7 @@ SYMBOLS = {
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    "sim3opt_preconditioner_in_use": (C.c_int, [_vp]),
     "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
@@ -388,6 +389,12 @@ class Graph:
         self._chk(self._L.sim3opt_solve(self._g, float(lam), _p(x, _dp), C.byref(it),
                                         C.byref(rr)))
         return x, it.value, rr.value
+
+    def preconditioner_in_use(self):
+        rc = self._L.sim3opt_preconditioner_in_use(self._g)
+        if rc < 0:
+            self._chk(rc)
+        return rc
 
     def amg_hierarchy(self):
         """(rows per level, blocks per level, level-1 row of every level-0 block row); host only."""
