@@ -133,7 +133,8 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
                                                      double* __restrict__ r_c,
                                                      const double* __restrict__ Minv_c,
                                                      double* __restrict__ x_c,
-                                                     const DevScalars* __restrict__ sc) {
+                                                     const DevScalars* __restrict__ sc, int row_lo,
+                                                     int row_hi) {
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
     const int e0 = act ? mptr[a] : 0, e1 = act ? mptr[a + 1] : 0;
     double acc = 0.0;
     for (int e = e0; __any(e < e1); ++e) {
-      const bool on = e < e1;
-      const int i = on ? mem[e] : 0;
+      const int i = e < e1 ? mem[e] : 0;
+      // multi-GPU: a rank sums the members it owns; the partial sums are all-reduced afterwards
+      const bool on = e < e1 && i >= row_lo && i < row_hi;
       const double tv = on ? t_f[(size_t)7 * i + rr] : 0.0;
       if (HASP) {
 #pragma unroll
@@ -167,6 +169,27 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
       }
       if (act) x_c[(size_t)7 * a + rr] = xv;
     }
+  }
+}
+
+// x = Minv r, 63 lanes = 9 block rows x 7 (multi-GPU: after the all-reduce of the restricted residual)
+__global__ __launch_bounds__(WG) void k_amg_bjapply(int nb, const double* __restrict__ Minv,
+                                                    const double* __restrict__ r,
+                                                    double* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane / 7, rr = lane % 7, base = lane - rr;
+  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
+    const int row = row0 + sub;
+    const bool act = lane < 63 && row < nb;
+    const double rv = act ? r[(size_t)7 * row + rr] : 0.0;
+    double xv = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc) {
+      const double rc = __shfl(rv, base + cc);
+      if (act) xv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
+    }
+    if (act) x[(size_t)7 * row + rr] = xv;
   }
 }
 

@@ -113,6 +113,11 @@ __global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa
   }
 }
 
+// multi-GPU: the breakdown flag is rank-local (a non-SPD block on one rank's rows); the ranks agree
+// on it through a max all-reduce of tmp_pq so that they keep taking the same branches
+__global__ void k_fail_to_double(DevScalars* sc) { sc->tmp_pq = sc->fail ? 1.0 : 0.0; }
+__global__ void k_double_to_fail(DevScalars* sc) { if (sc->tmp_pq > 0.0) sc->fail = 1; }
+
 // ------------------------------------------------------------------------------------------
 // per-edge residual kernels
 // ------------------------------------------------------------------------------------------
@@ -986,6 +991,8 @@ class Engine {
   double amg_omega = 0.9;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
   int amg_visits[AMG_MAX_LEVELS + 1];  // cycles spent on level l per visit of level l-1 (1 = V, 2 = W)
   bool amg_additive = false;           // level 0 additive: no fine-level matrix pass in the cycle
+  int amg_status = 0;                  // first collective error inside a cycle
+  std::string amg_err;
   // hipGraph of `graph_iters` PCG iterations (single GPU, untimed runs): replayed per chunk
   hipGraphExec_t pcg_graph = nullptr;
   int pcg_graph_kind = -1;
@@ -1159,7 +1166,7 @@ class Engine {
     }
     if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
     const double avg_off = nb > 0 ? (double)(nnzb - nb) / nb : 0.0;
-    if (comm.world == 1 && !use_chain &&
+    if (!use_chain &&
         (opt.preconditioner == 2 ||
          (opt.preconditioner < 0 && opt.fix_small_angle_b != 0 && nb >= 20000 && avg_off >= 8.0))) {
       int rc = amg_init(s, err);
@@ -1259,7 +1266,8 @@ class Engine {
     L0.nb = nb; L0.nnzb = nnzb;
     L0.rowptr = d_rowptr; L0.colidx = d_colidx; L0.wrow = d_wrow; L0.span_grid = span_grid;
     L0.vals = d_vals; L0.Minv = d_Minv; L0.r = d_r; L0.x = d_z;
-    AMGCHK(amg_alloc(d_az, (size_t)n, err));
+    // (padded like the PCG vectors: the multi-GPU all-gather runs in place with equal counts)
+    AMGCHK(amg_alloc(d_az, std::max<size_t>((size_t)n, (size_t)comm.world * (size_t)(offs[1] - offs[0])), err));
     AMGCHK(amg_alloc(d_P, (size_t)49 * nb, err));
     AMGCHK(amg_up(d_row2v, s.row2vertex, err));
     L0.t = d_az;
@@ -1317,6 +1325,12 @@ class Engine {
       if (l == 0) {
         hipLaunchKernelGGL((k_amg_galerkin<true>), dim3(gg), dim3(WG), 0, stream, (int)Cc.nnzb, F.gptr,
                            F.gblk, F.grow, F.colidx, F.vals, d_P, Cc.vals);
+        if (comm.active()) {
+          // a rank holds the blocks of its own rows (the others are zero): the products above are
+          // partial sums; summed over the ranks, level 1 and everything below is replicated
+          int rc = comm.allreduce(Cc.vals, (int)(49 * Cc.nnzb), 0, stream, err);
+          if (rc) return rc;
+        }
         hipLaunchKernelGGL((k_amg_wsum<true>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
                            d_P, Cc.W);
       } else {
@@ -1338,7 +1352,8 @@ class Engine {
     const int nl = (int)amg.size();
     for (int l = 0; l < nl; ++l) {
       const AmgLevel& L = amg[l];
-      hipLaunchKernelGGL(k_jacobi, dim3(std::max(1, (L.nb + WG - 1) / WG)), dim3(WG), 0, stream, 0, L.nb,
+      const int lo = l == 0 ? r0 : 0, hi = l == 0 ? r1 : L.nb;  // level 0 is row-partitioned
+      hipLaunchKernelGGL(k_jacobi, dim3(std::max(1, (hi - lo + WG - 1) / WG)), dim3(WG), 0, stream, lo, hi,
                          L.rowptr, L.vals, lambda, L.Minv, d_sc, l == 0 && amg_additive ? 1.0 : amg_omega,
                          L.diagH, L.W);
     }
@@ -1366,13 +1381,22 @@ class Engine {
     const AmgLevel& F = amg[l];
     const AmgLevel& Cc = amg[l + 1];
     const int gr = grid_for((Cc.nb + 8) / 9, 4);
+    const bool split = l == 0 && comm.active();  // level 0 is row-partitioned: partial sums
     const double* Minv_c = l + 2 < (int)amg.size() ? Cc.Minv : nullptr;  // coarsest: solved exactly
     if (l == 0)
       hipLaunchKernelGGL((k_amg_restrict<true>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
-                         d_P, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)d_sc);
+                         d_P, t, Cc.r, split ? (const double*)nullptr : Minv_c, Cc.x,
+                         (const DevScalars*)d_sc, r0, r1);
     else
       hipLaunchKernelGGL((k_amg_restrict<false>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
-                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)nullptr);
+                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)nullptr, 0,
+                         F.nb);
+    if (split) {
+      if (amg_status == SIM3OPT_OK) amg_status = comm.allreduce(Cc.r, 7 * Cc.nb, 0, stream, amg_err);
+      if (Minv_c)
+        hipLaunchKernelGGL(k_amg_bjapply, dim3(gr), dim3(WG), 0, stream, Cc.nb, Minv_c,
+                           (const double*)Cc.r, Cc.x);
+    }
   }
   void amg_prolong(int l, const double* xc, const double* xin, double* xout) {
     const AmgLevel& F = amg[l];
@@ -1420,13 +1444,27 @@ class Engine {
   // d_az = M^-1 d_r; on entry d_z = Minv_0 d_r (written by the PCG step).  Multiplicative: one
   // V(1,1) (or W) cycle from that iterate.  Additive on level 0 (no fine-level matrix pass in the
   // preconditioner): M^-1 = D^-1 + P (coarse cycle) P^T.
-  void amg_apply() {
+  // Multi-GPU: level 0 is row-partitioned like the PCG (its matrix passes need the whole iterate:
+  // one all-gather of d_z before, one of d_az after; the restricted residual is all-reduced), the
+  // coarse levels are replicated and every rank runs the same coarse cycle.
+  int amg_apply(std::string& err) {
+    amg_status = SIM3OPT_OK;
+    if (comm.active()) {
+      int rc = comm.allgatherv(d_z, offs, stream, err);
+      if (rc) return rc;
+    }
     if (amg_additive) {
       amg_restrict(0, d_r);
       amg_prolong(0, amg_coarse(0), d_z, d_az);
     } else {
       amg_cycle(0, d_z, d_az);
     }
+    if (amg_status != SIM3OPT_OK) {
+      err = amg_err;
+      return amg_status;
+    }
+    if (comm.active()) return comm.allgatherv(d_az, offs, stream, err);
+    return SIM3OPT_OK;
   }
 
   // ---- building blocks ----
@@ -1520,6 +1558,14 @@ class Engine {
   // Preconditioned CG on (H + lambda I) x = b in the single-reduction form (k_pcg_step); the
   // result stays in d_x.  Two launches and one reduction point per iteration; the host only polls
   // a 100-byte struct every `pcg_check_every` iterations.
+  int agree_on_fail(std::string& err) {  // multi-GPU: fail on any rank = fail on all
+    hipLaunchKernelGGL(k_fail_to_double, dim3(1), dim3(1), 0, stream, d_sc);
+    int rc = comm.allreduce(&d_sc->tmp_pq, 1, 1, stream, err);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_double_to_fail, dim3(1), dim3(1), 0, stream, d_sc);
+    return SIM3OPT_OK;
+  }
+
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
     if (use_amg || use_chain) {
       // the block-tridiagonal factorisation (or the multigrid's coarsest-level inverse) can meet a
@@ -1579,6 +1625,10 @@ class Engine {
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(WG), 0, stream, r0, r1, d_b, Minv_arg, d_x, d_r,
                        d_z, d_p, d_s);
     if (use_chain || use_mg) {
+      if (multi) {
+        rc = agree_on_fail(err);
+        if (rc) return rc;
+      }
       rc = fetch_scalars(err);  // did the factorisation succeed?
       if (rc) return rc;
       if (h_sc->fail) {
@@ -1594,11 +1644,13 @@ class Engine {
       if (use_chain)
         hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg, d_Minv,
                            d_Gm, d_r, d_z, (const DevScalars*)nullptr);
-      else
-        amg_apply();
+      else {
+        rc = amg_apply(err);
+        if (rc) return rc;
+      }
     }
     HIPCHK(hipGetLastError());
-    if (multi) {
+    if (multi && !use_mg) {  // (the multigrid cycle gathers its own operands)
       rc = comm.allgatherv(d_z, offs, stream, err);
       if (rc) return rc;
     }
@@ -1624,7 +1676,7 @@ class Engine {
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
                              d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
-        if (use_mg) amg_apply();
+        if (use_mg) (void)amg_apply(err);  // single GPU here: no collectives inside
       }
       HIPCHK(hipStreamEndCapture(stream, &gr));
       HIPCHK(hipGraphInstantiate(&pcg_graph, gr, nullptr, nullptr, 0));
@@ -1663,8 +1715,11 @@ class Engine {
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
                              d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
-        if (use_mg) amg_apply();
-        if (multi) {  // the next SpMV gathers z from every rank
+        if (use_mg) {
+          rc = amg_apply(err);
+          if (rc) return rc;
+        }
+        if (multi && !use_mg) {  // the next SpMV gathers z from every rank
           rc = comm.allgatherv(d_z, offs, stream, err);
           if (rc) return rc;
         }
@@ -1675,6 +1730,10 @@ class Engine {
     }
     if (multi) {  // every rank updates its replica of all estimates
       rc = comm.allgatherv(d_x, offs, stream, err);
+      if (rc) return rc;
+      rc = agree_on_fail(err);
+      if (rc) return rc;
+      rc = fetch_scalars(err);
       if (rc) return rc;
     }
     kt.n_pcg_vec += h_sc->iter;

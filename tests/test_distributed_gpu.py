@@ -20,24 +20,27 @@ def _free_port():
     return p
 
 
-def _graph():
+def _graph(prec=-1):
     from sim3opt_amd import synth
     synth.DRIFT_TARGET = 0.05
+    if prec == 2:  # large enough for a three-level hierarchy (1499 -> ~180 -> ~22 rows)
+        return synth.manhattan(1500, 15000, dims=(12, 12, 10))
     return synth.manhattan(300, 2500, dims=(7, 7, 4), per_cell=4)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, prec=-1):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import dist_helpers as D
     from sim3opt_amd import lib as L
     D.init(rank, world, port)
-    g = _graph()
-    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12)
+    g = _graph(prec)
+    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     G.comm_init_callbacks(rank, world, D.allreduce, D.allgatherv)
     G.initialize()
+    assert G.preconditioner_in_use() == (2 if prec == 2 else 0)
     lo, hi = G.local_rows()
     chi0 = G.chi2()
     n = G.optimize(4)
@@ -55,14 +58,16 @@ def _worker(rank, world, port, out):
              pcg=[s.pcg_iters for s in st])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_process_row_partition_matches_single(tmp_path, world):
+@pytest.mark.parametrize("world,prec", [(2, -1), (3, -1), (2, 2), (3, 2)])
+def test_two_process_row_partition_matches_single(tmp_path, world, prec):
+    """prec = 2: the multigrid preconditioner with its level 0 row-partitioned (all-reduced Galerkin
+    products and restricted residuals, replicated coarse levels)."""
     from sim3opt_amd import lib as L, synth
     out = str(tmp_path / "r")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True)
     res = [np.load(out + f".{r}.npz") for r in range(world)]
-    g = _graph()
-    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12)
+    g = _graph(prec)
+    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     G.initialize()
@@ -74,6 +79,9 @@ def test_two_process_row_partition_matches_single(tmp_path, world):
     assert res[0]["rows"][0] == 0 and res[-1]["rows"][1] == nb
     for a, b in zip(res[:-1], res[1:]):
         assert a["rows"][1] == b["rows"][0]
+    if prec == 2:  # same hierarchy, same convergence: iteration counts within a couple of steps
+        for r in res:
+            assert all(abs(int(a) - int(b.pcg_iters)) <= 3 for a, b in zip(r["pcg"], st))
     for r in res:
         # all ranks hold identical results (same reductions on every rank)
         assert np.array_equal(r["states"], res[0]["states"])
@@ -81,29 +89,32 @@ def test_two_process_row_partition_matches_single(tmp_path, world):
         assert abs(float(r["chi0"]) - chi0) < 1e-10 * chi0
         # vs the single-process run: only summation order differs
         assert np.allclose(r["chi"], [s.chi2_after for s in st], rtol=1e-7)
-        assert synth.rmse(r["states"], G.get_vertices()) < 1e-6
+        # (1500-vertex graph of the multigrid case: PCG-tolerance-level differences times the
+        # conditioning of the late, lightly damped systems)
+        assert synth.rmse(r["states"], G.get_vertices()) < (2e-5 if prec == 2 else 1e-6)
         assert abs(float(r["regrown_chi"]) - float(res[0]["regrown_chi"])) < 1e-12 * float(res[0]["regrown_chi"])
 
 
-def test_rccl_transport_single_rank_selftest(monkeypatch):
+@pytest.mark.parametrize("prec", [-1, 2])
+def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     """The RCCL transport (dlopen, ncclCommInitRank, in-place ncclAllReduce, grouped in-place
     ncclBroadcast on the engine's stream) exercised with one rank: every collective of the
     multi-GPU branch runs and must reproduce the plain single-GPU result bit for bit."""
     import ctypes as C
     from sim3opt_amd import lib as L
     monkeypatch.setenv("SIM3OPT_FORCE_COMM", "1")
-    g = _graph()
+    g = _graph(prec)
     uid = np.zeros(128, dtype=np.uint8)
     assert L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) == L.OK
     assert uid.any()
-    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10)
+    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec)
     A.add_vertices(g["states"], g["fixed"])
     A.add_edges(g["v0"], g["v1"], g["meas"])
     A.comm_init_rccl(0, 1, uid)
     A.initialize()
     A.optimize(3)
     monkeypatch.delenv("SIM3OPT_FORCE_COMM")
-    B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10)
+    B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec)
     B.add_vertices(g["states"], g["fixed"])
     B.add_edges(g["v0"], g["v1"], g["meas"])
     B.initialize()
