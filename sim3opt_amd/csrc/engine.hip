@@ -68,6 +68,7 @@ struct DevScalars {
   double tmp_rz;     // multi-GPU: r.z summed over ranks  } per PCG iteration
   double gam_last;   // r.z seen by the last executed step (reported relative residual)
   double lambda;     // damping of the current solve (read by the captured PCG launches)
+  long long n_spmv_work;  // PCG SpMV launches that did their work (launches after `done` return at once)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -483,7 +484,10 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
     if (sc->done) return;
     if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
     // the previous update was the last allowed one: later launches become no-ops
-    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0 && sc->stop) sc->done = 1;
+    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+      if (sc->stop) sc->done = 1;
+      sc->n_spmv_work += 1;  // (launches are stream-ordered: one writer at a time)
+    }
   }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -1223,12 +1227,20 @@ class Engine {
     return SIM3OPT_OK;
   }
   // after a stream sync: fold the recorded SpMV event pairs into the accumulators
+  // (h_sc must be fresh).  Launches enqueued after the solve finished return at once; they are
+  // left out of the launch count -- their few microseconds stay in the sum, so the average errs on
+  // the slow side -- otherwise the per-launch figure would be flattered by up to pcg_check_every - 1
+  // empty launches per solve.
+  long long spmv_work_seen = 0;
   int pool_drain(std::string& err) {
+    if (pool_used > 0) {
+      kt.n_spmv += (int64_t)std::max<long long>(0, h_sc->n_spmv_work - spmv_work_seen);
+      spmv_work_seen = h_sc->n_spmv_work;
+    }
     for (size_t i = 0; i + 1 < pool_used; i += 2) {
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, pool[i], pool[i + 1]));
       kt.ms_spmv += ms;
-      kt.n_spmv += 1;
     }
     pool_used = 0;
     return SIM3OPT_OK;
@@ -1689,6 +1701,8 @@ class Engine {
       if (opt.time_kernels) {
         rc = pool_drain(err);
         if (rc) return rc;
+      } else {
+        spmv_work_seen = h_sc->n_spmv_work;
       }
       if (h_sc->done || h_sc->stop || h_sc->fail || it >= max_it) break;
       if (graphed && it > 0 && par == 1 && max_it - it >= graph_iters) {
