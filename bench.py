@@ -227,7 +227,7 @@ def main():
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         except Exception:
             traffic = None
-        prec_name = {0: "block-Jacobi", 1: "chain-segment", 2: "aggregation-multigrid (W-cycle)"}[
+        prec_name = {0: "block-Jacobi", 1: "chain-segment", 2: "aggregation-multigrid"}[
             G.preconditioner_in_use()]
         roof = None
         if kt.n_spmv > 0:

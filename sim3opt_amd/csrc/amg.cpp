@@ -133,10 +133,13 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
   const int32_t* rowptr = rowptr0;
   const int32_t* colidx = colidx0;
   std::vector<int64_t> bw, bw_next;  // level-0 blocks behind each block of the current level
+  int max_coarsest = AMG_MAX_COARSEST;
+  if (const char* ev = std::getenv("SIM3OPT_AMG_COARSEST"))  // tuning knob
+    max_coarsest = std::max(8, std::min(AMG_MAX_COARSEST, std::atoi(ev)));
   for (;;) {
     AmgLevelHost& L = levels.back();
     const int32_t nb = L.nb;
-    if (nb <= AMG_MAX_COARSEST) return levels.size() > 1 || (why = "system already tiny", false);
+    if (nb <= max_coarsest) return levels.size() > 1 || (why = "system already tiny", false);
     if ((int)levels.size() >= AMG_MAX_LEVELS) {
       why = "too many levels";
       return false;
@@ -151,7 +154,7 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
       const size_t l = std::min(levels.size() - 1, std::strlen(ev) - 1);
       if (std::strlen(ev) > 0 && ev[l] >= '1' && ev[l] <= '6') npass = ev[l] - '0';
     }
-    for (int pass = 0; pass < npass && nc > AMG_MAX_COARSEST / 2; ++pass) {
+    for (int pass = 0; pass < npass && nc > max_coarsest / 2; ++pass) {
       std::vector<int32_t> cid;
       const int32_t m = match_pass(g, cid);
       for (int32_t& a : agg) a = cid[a];

@@ -30,7 +30,7 @@ struct AmgLevelHost {
   std::vector<int32_t> gblk, grow; // ... as (block index, block row) of THIS level, ascending block index
 };
 
-constexpr int AMG_MAX_COARSEST = 64;  // block rows of the dense coarsest level (448 unknowns)
+constexpr int AMG_MAX_COARSEST = 256;  // block rows of the dense coarsest level (1792 unknowns)
 constexpr int AMG_MAX_LEVELS = 10;
 
 // Builds the level patterns from the level-0 block-CSR pattern.  Returns false (with a reason)

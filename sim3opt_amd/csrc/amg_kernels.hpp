@@ -172,6 +172,45 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
   }
 }
 
+// Level-0 restriction, one wavefront per aggregate: lane (m, c) = entry l49 = m + 7c of P_i (one
+// coalesced 392-byte read per member), r_c[c] = sum_i sum_m P_i[m][c] t_i[m]; then the coarse
+// level's first smoothing step x_c = Minv_c r_c with Minv_c read the same way.
+__global__ __launch_bounds__(WG) void k_amg_restrict0(int nc, const int32_t* __restrict__ mptr,
+                                                      const int32_t* __restrict__ mem,
+                                                      const double* __restrict__ P,
+                                                      const double* __restrict__ t_f,
+                                                      double* __restrict__ r_c,
+                                                      const double* __restrict__ Minv_c,
+                                                      double* __restrict__ x_c,
+                                                      const DevScalars* __restrict__ sc, int row_lo,
+                                                      int row_hi) {
+  if (sc && sc->done) return;
+  const int lane = threadIdx.x & 63;
+  const int a = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (a >= nc) return;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int m = l49 % 7, c = l49 / 7;
+  double acc = 0.0;
+  const int e0 = mptr[a], e1 = mptr[a + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int i = mem[e];
+    if (i < row_lo || i >= row_hi) continue;  // wave-uniform (multi-GPU: members of other ranks)
+    acc += P[(size_t)49 * i + l49] * t_f[(size_t)7 * i + m];
+  }
+  // sum over m inside each group of 7 lanes (fixed c): lanes 7c .. 7c+6
+  double rc = 0.0;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) rc += __shfl(acc, 7 * c + q);
+  if (lane < 49 && m == 0) r_c[(size_t)7 * a + c] = rc;
+  if (Minv_c) {  // x_c[m] = sum_c Minv[m][c] r_c[c]; lane (m, c) holds r_c[c]
+    const double pr = Minv_c[(size_t)49 * a + l49] * rc;  // symmetric: entry (m, c)
+    double xv = pr;
+#pragma unroll
+    for (int q = 1; q < 7; ++q) xv += __shfl(pr, m + 7 * ((c + q) % 7));
+    if (lane < 7) x_c[(size_t)7 * a + lane] = xv;
+  }
+}
+
 // x = Minv r, 63 lanes = 9 block rows x 7 (multi-GPU: after the all-reduce of the restricted residual)
 __global__ __launch_bounds__(WG) void k_amg_bjapply(int nb, const double* __restrict__ Minv,
                                                     const double* __restrict__ r,
@@ -221,66 +260,106 @@ __global__ __launch_bounds__(WG) void k_amg_prolong(int nb, const int32_t* __res
   }
 }
 
-// Coarsest level: dense copy of its block-CSR matrix (unique columns per row, damping already in
-// the diagonal blocks) inverted in place by Gauss-Jordan without pivoting (SPD: positive pivots).
-// One workgroup; n = 7 nb <= 448.  Pivot row and column go through LDS: two barriers per pivot.
-constexpr int AMG_DENSE_WG = 1024;
-constexpr int AMG_DENSE_MAX_N = 448;
-__global__ __launch_bounds__(AMG_DENSE_WG) void k_amg_dense_invert(int nb,
-                                                                   const int32_t* __restrict__ rowptr,
-                                                                   const int32_t* __restrict__ colidx,
-                                                                   const double* __restrict__ vals,
-                                                                   double* __restrict__ Ainv,
-                                                                   DevScalars* sc) {
-  __shared__ double rowk[AMG_DENSE_MAX_N], colk[AMG_DENSE_MAX_N];
-  __shared__ int bad;
-  const int n = 7 * nb, tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int idx = tid; idx < n * n; idx += AMG_DENSE_WG) Ainv[idx] = 0.0;
-  __syncthreads();
-  for (int i = 0; i < nb; ++i) {
-    const int k0 = rowptr[i], cnt = (rowptr[i + 1] - k0) * 49;
-    for (int t = tid; t < cnt; t += AMG_DENSE_WG) {
-      const int k = k0 + t / 49, e = t % 49;
-      Ainv[(size_t)(7 * i + e % 7) * n + 7 * colidx[k] + e / 7] = vals[(size_t)49 * k + e];
+// Coarsest level (<= AMG_MAX_COARSEST block rows): dense copy of its block-CSR matrix (unique
+// columns per row, damping already in the diagonal blocks) ...
+constexpr int AMG_DENSE_MAX_N = 7 * AMG_MAX_COARSEST;
+__global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ colidx,
+                                                       const double* __restrict__ vals,
+                                                       double* __restrict__ A) {
+  const int n = 7 * nb;
+  const int nnz = 49 * rowptr[nb];
+  for (int t = blockIdx.x * WG + threadIdx.x; t < nnz; t += gridDim.x * WG) {
+    const int k = t / 49, e = t % 49;
+    int lo = 0, hi = nb;  // block row of block k: last i with rowptr[i] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= k) lo = mid; else hi = mid;
     }
+    A[(size_t)(7 * lo + e % 7) * n + 7 * colidx[k] + e / 7] = vals[(size_t)49 * k + e];
   }
-  __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    const double piv = Ainv[(size_t)k * n + k];
-    if (tid == 0 && !(piv > 0.0)) bad = 1;
-    const double d = 1.0 / piv;
-    for (int j = tid; j < n; j += AMG_DENSE_WG) {
-      rowk[j] = Ainv[(size_t)k * n + j] * d;
-      colk[j] = Ainv[(size_t)j * n + k];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += AMG_DENSE_WG) {
-      const int i = idx / n, j = idx - i * n;
-      double v;
-      if (i == k) v = j == k ? d : rowk[j];
-      else if (j == k) v = -colk[i] * d;
-      else v = Ainv[idx] - colk[i] * rowk[j];
-      Ainv[idx] = v;
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && bad) sc->fail = 1;
 }
 
-// x = Ainv r on the coarsest level (Ainv symmetric: column reads are coalesced)
-__global__ __launch_bounds__(512) void k_amg_dense_apply(int n, const double* __restrict__ Ainv,
-                                                         const double* __restrict__ r,
-                                                         double* __restrict__ x,
-                                                         const DevScalars* __restrict__ sc) {
-  __shared__ double rs[AMG_DENSE_MAX_N];
-  if (sc && sc->done) return;
+// ... inverted by Gauss-Jordan with 7x7 block pivots and no pivot search (SPD: positive pivots),
+// one launch per block pivot, out of place (B = step_k(A), buffers ping-pong) so that no workgroup
+// reads what another one overwrites:
+//   P = A_kk^-1;  B_kk = P;  B_kj = P A_kj;  B_ik = -A_ik P;  B_ij = A_ij - A_ik (P A_kj)
+// A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS.
+__global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int kb, const double* __restrict__ A,
+                                                          double* __restrict__ B, DevScalars* sc) {
+  __shared__ double P[7][7];
+  __shared__ double rowk[7][64];  // (P A_k.) for the tile's columns
+  __shared__ double colk[64][7];  // A_.k for the tile's rows
   const int tid = threadIdx.x;
-  if (tid < n) rs[tid] = r[tid];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64, k0 = 7 * kb;
+  if (tid == 0) {
+    double a[7][7];
+    for (int r = 0; r < 7; ++r)
+      for (int c = 0; c < 7; ++c) a[r][c] = A[(size_t)(k0 + r) * n + k0 + c];
+    bool spd = true;
+    for (int k = 0; k < 7; ++k) {
+      if (!(a[k][k] > 0.0)) spd = false;
+      const double d = 1.0 / a[k][k];
+      for (int j = 0; j < 7; ++j)
+        if (j != k) a[k][j] *= d;
+      for (int i = 0; i < 7; ++i)
+        if (i != k) {
+          const double f = a[i][k];
+          for (int j = 0; j < 7; ++j)
+            if (j != k) a[i][j] -= f * a[k][j];
+          a[i][k] = -f * d;
+        }
+      a[k][k] = d;
+    }
+    for (int r = 0; r < 7; ++r)
+      for (int c = 0; c < 7; ++c) P[r][c] = a[r][c];
+    if (!spd && blockIdx.x == 0 && blockIdx.y == 0) sc->fail = 1;
+  }
+  for (int t = tid; t < 64 * 7; t += WG) {  // A_.k slice
+    const int i = t / 7, m = t % 7;
+    colk[i][m] = i0 + i < n ? A[(size_t)(i0 + i) * n + k0 + m] : 0.0;
+  }
   __syncthreads();
-  if (tid >= n) return;
-  double acc = 0.0;
-  for (int j = 0; j < n; ++j) acc += Ainv[(size_t)j * n + tid] * rs[j];
-  x[tid] = acc;
+  for (int t = tid; t < 7 * 64; t += WG) {  // (P A_k.) slice
+    const int m = t / 64, j = t % 64;
+    double acc = 0.0;
+    if (j0 + j < n)
+      for (int q = 0; q < 7; ++q) acc += P[m][q] * A[(size_t)(k0 + q) * n + j0 + j];
+    rowk[m][j] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < 64 * 64; t += WG) {
+    const int il = t / 64, jl = t % 64, i = i0 + il, j = j0 + jl;
+    if (i >= n || j >= n) continue;
+    const bool ik = i >= k0 && i < k0 + 7, jk = j >= k0 && j < k0 + 7;
+    double v;
+    if (ik && jk) {
+      v = P[i - k0][j - k0];
+    } else if (ik) {
+      v = rowk[i - k0][jl];
+    } else if (jk) {
+      v = 0.0;
+      for (int m = 0; m < 7; ++m) v -= colk[il][m] * P[m][j - k0];
+    } else {
+      v = A[(size_t)i * n + j];
+      for (int m = 0; m < 7; ++m) v -= colk[il][m] * rowk[m][jl];
+    }
+    B[(size_t)i * n + j] = v;
+  }
 }
 
+// x = Ainv r on the coarsest level: a wavefront per row, lanes along the row (coalesced; r is a few
+// KB and stays in cache)
+__global__ __launch_bounds__(WG) void k_amg_dense_apply(int n, const double* __restrict__ Ainv,
+                                                        const double* __restrict__ r,
+                                                        double* __restrict__ x,
+                                                        const DevScalars* __restrict__ sc) {
+  if (sc && sc->done) return;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += Ainv[(size_t)i * n + j] * r[j];
+    acc = wave_sum(acc);
+    if (lane == 0) x[i] = acc;
+  }
+}

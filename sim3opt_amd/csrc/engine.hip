@@ -989,7 +989,7 @@ class Engine {
   };
   std::vector<AmgLevel> amg;
   std::vector<void*> amg_owned;
-  double *d_P = nullptr, *d_Ainv = nullptr, *d_az = nullptr;
+  double *d_P = nullptr, *d_Ainv = nullptr, *d_Ainv2 = nullptr, *d_az = nullptr;
   int32_t* d_row2v = nullptr;
   bool use_amg = false, amg_stale = true;
   double amg_omega = 0.9;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
@@ -1160,7 +1160,12 @@ class Engine {
     // multigrid for large loop-rich graphs (config 3: every vertex tied to ~20 neighbours), where
     // block-Jacobi PCG needs thousands of iterations; same well-posedness condition as the chain
     if (const char* ev = std::getenv("SIM3OPT_AMG_OMEGA")) amg_omega = std::max(0.1, std::min(0.95, std::atof(ev)));
-    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = 2;  // W-cycle (measured: DESIGN.md)
+    // defaults (measured).  One GPU: additive on level 0 (one level-0 matrix pass per
+    // PCG iteration instead of three, about twice the iterations), level 1 once and deeper levels
+    // twice per visit.  Row-partitioned: multiplicative (half the iterations = half the collectives),
+    // deeper levels three times per visit.
+    amg_additive = comm.world == 1;
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = l <= 1 ? 1 : (amg_additive ? 2 : 3);
     if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) {  // e.g. "122": visits of levels 1, 2, 3...
       int last = 1;
       for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
@@ -1314,6 +1319,7 @@ class Engine {
     }
     const size_t nc = (size_t)7 * amg[nl - 1].nb;
     AMGCHK(amg_alloc(d_Ainv, nc * nc, err));
+    AMGCHK(amg_alloc(d_Ainv2, nc * nc, err));
 #undef AMGCHK
     if (opt.verbose) {
       std::fprintf(stderr, "sim3opt: multigrid levels (rows/blocks):");
@@ -1369,9 +1375,24 @@ class Engine {
                          L.rowptr, L.vals, lambda, L.Minv, d_sc, l == 0 && amg_additive ? 1.0 : amg_omega,
                          L.diagH, L.W);
     }
+    // dense inverse of the coarsest level: one launch per 7x7 block pivot, buffers ping-pong
     const AmgLevel& Lc = amg[nl - 1];
-    hipLaunchKernelGGL(k_amg_dense_invert, dim3(1), dim3(AMG_DENSE_WG), 0, stream, Lc.nb, Lc.rowptr,
-                       Lc.colidx, Lc.vals, d_Ainv, d_sc);
+    const int nd = 7 * Lc.nb;
+    (void)hipMemsetAsync(d_Ainv2, 0, sizeof(double) * (size_t)nd * nd, stream);
+    hipLaunchKernelGGL(k_amg_dense_fill, dim3(grid_for(49 * Lc.nnzb, WG)), dim3(WG), 0, stream, Lc.nb,
+                       Lc.rowptr, Lc.colidx, Lc.vals, d_Ainv2);
+    double *src = d_Ainv2, *dst = d_Ainv;
+    if (Lc.nb % 2 == 0) {  // an even number of steps would end in d_Ainv2: start from d_Ainv instead
+      (void)hipMemcpyAsync(d_Ainv, d_Ainv2, sizeof(double) * (size_t)nd * nd, hipMemcpyDeviceToDevice, stream);
+      src = d_Ainv;
+      dst = d_Ainv2;
+    }
+    const dim3 gt((nd + 63) / 64, (nd + 63) / 64);
+    for (int kb = 0; kb < Lc.nb; ++kb) {
+      hipLaunchKernelGGL(k_amg_dense_gj_step, gt, dim3(WG), 0, stream, nd, kb, (const double*)src, dst,
+                         d_sc);
+      std::swap(src, dst);
+    }  // the inverse is in d_Ainv
   }
 
   void spmv_mode(const AmgLevel& L, int mode, int level, const double* v, double* out,
@@ -1396,8 +1417,8 @@ class Engine {
     const bool split = l == 0 && comm.active();  // level 0 is row-partitioned: partial sums
     const double* Minv_c = l + 2 < (int)amg.size() ? Cc.Minv : nullptr;  // coarsest: solved exactly
     if (l == 0)
-      hipLaunchKernelGGL((k_amg_restrict<true>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
-                         d_P, t, Cc.r, split ? (const double*)nullptr : Minv_c, Cc.x,
+      hipLaunchKernelGGL(k_amg_restrict0, dim3((Cc.nb + 3) / 4), dim3(WG), 0, stream, Cc.nb, F.mptr,
+                         F.mem, d_P, t, Cc.r, split ? (const double*)nullptr : Minv_c, Cc.x,
                          (const DevScalars*)d_sc, r0, r1);
     else
       hipLaunchKernelGGL((k_amg_restrict<false>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
@@ -1427,8 +1448,8 @@ class Engine {
     const int nl = (int)amg.size();
     const AmgLevel& Cc = amg[l + 1];
     if (l + 2 == nl) {
-      hipLaunchKernelGGL(k_amg_dense_apply, dim3(1), dim3(512), 0, stream, 7 * Cc.nb, d_Ainv, Cc.r,
-                         Cc.x, (const DevScalars*)nullptr);
+      hipLaunchKernelGGL(k_amg_dense_apply, dim3(std::max(1, std::min(256, (7 * Cc.nb + 3) / 4))), dim3(WG),
+                         0, stream, 7 * Cc.nb, d_Ainv, Cc.r, Cc.x, (const DevScalars*)nullptr);
       return Cc.x;
     }
     double* res = amg_cycle(l + 1, Cc.x, Cc.t);
@@ -1666,7 +1687,9 @@ class Engine {
       rc = comm.allgatherv(d_z, offs, stream, err);
       if (rc) return rc;
     }
-    const int chunk = std::max(1, opt.pcg_check_every);
+    // (a multigrid iteration is ~1 ms of GPU work and its coarse launches run even after `done`:
+    // poll more often)
+    const int chunk = use_mg ? std::min(4, std::max(1, opt.pcg_check_every)) : std::max(1, opt.pcg_check_every);
     int it = 0, par = 0;
     // Launch-bound regime (small graphs: two ~3 us kernels per iteration): replay a captured
     // hipGraph of PCG_GRAPH_ITERS iterations instead of enqueueing them one by one.  The first

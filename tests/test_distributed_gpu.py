@@ -59,7 +59,7 @@ def _worker(rank, world, port, out, prec=-1):
 
 
 @pytest.mark.parametrize("world,prec", [(2, -1), (3, -1), (2, 2), (3, 2)])
-def test_two_process_row_partition_matches_single(tmp_path, world, prec):
+def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec):
     """prec = 2: the multigrid preconditioner with its level 0 row-partitioned (all-reduced Galerkin
     products and restricted residuals, replicated coarse levels)."""
     from sim3opt_amd import lib as L, synth
@@ -67,6 +67,9 @@ def test_two_process_row_partition_matches_single(tmp_path, world, prec):
     mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True)
     res = [np.load(out + f".{r}.npz") for r in range(world)]
     g = _graph(prec)
+    if prec == 2:  # the single-GPU default cycle is the additive one; compare like with like
+        monkeypatch.setenv("SIM3OPT_AMG_ADDITIVE", "0")
+        monkeypatch.setenv("SIM3OPT_AMG_CYCLE", "13")
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])

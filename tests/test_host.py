@@ -192,7 +192,7 @@ def test_umeyama_alignment_and_kitti_original_map_rmse():
 
 def test_amg_hierarchy_structure():
     """Host set-up of the multigrid preconditioner (amg.cpp): pairwise matching coarsens a
-    Manhattan graph by ~8x per level down to <= 64 rows; aggregates are connected subsets of 8 block
+    Manhattan graph by ~8x per level down to <= 256 rows; aggregates are connected subsets of 8 block
     rows (a few larger ones where left-over rows joined a neighbour); a star graph (nothing to match after the hub) is refused."""
     from sim3opt_amd import synth
     g = synth.manhattan(3000, 30000, dims=(17, 17, 10))
@@ -201,7 +201,7 @@ def test_amg_hierarchy_structure():
     G.add_edges(g["v0"], g["v1"], g["meas"])
     rows, blocks, agg = G.amg_hierarchy()
     assert rows[0] == 2999 and blocks[0] == 2999 + 2 * 30000 - 2 * int(((g["v0"] == 0) | (g["v1"] == 0)).sum())
-    assert len(rows) >= 3 and rows[-1] <= 64
+    assert len(rows) >= 3 and rows[-1] <= 256
     assert all(rows[l + 1] <= rows[l] // 3 for l in range(len(rows) - 2))  # 3 matching passes per level
     assert all(blocks[l + 1] < blocks[l] for l in range(len(rows) - 1))
     agg = agg[:2999]
