@@ -69,7 +69,7 @@ typedef struct sim3opt_options {
                                        aggregates, Ad(S_v)-transported prolongation; single GPU),
                                        -1 = automatic, in the well-posed arithmetic only: chain for
                                        nearly pure chains (off-chain edges <= rows/64), multigrid for
-                                       >= 20000 free vertices with >= 8 off-diagonal blocks per row,
+                                       >= 2000 free vertices with >= 8 off-diagonal blocks per row,
                                        else block-Jacobi                                           */
   int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */

@@ -1177,7 +1177,7 @@ class Engine {
     const double avg_off = nb > 0 ? (double)(nnzb - nb) / nb : 0.0;
     if (!use_chain &&
         (opt.preconditioner == 2 ||
-         (opt.preconditioner < 0 && opt.fix_small_angle_b != 0 && nb >= 20000 && avg_off >= 8.0))) {
+         (opt.preconditioner < 0 && opt.fix_small_angle_b != 0 && nb >= 2000 && avg_off >= 8.0))) {
       int rc = amg_init(s, err);
       if (rc) return rc;
     }
