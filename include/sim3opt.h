@@ -65,11 +65,13 @@ typedef struct sim3opt_options {
   int32_t pcg_graph;        /* 1     replay the PCG iterations from a captured hipGraph (single GPU,
                                         time_kernels = 0); 0 = enqueue every launch               */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
-                                       2 = aggregation multigrid V(1,1) cycle (pairwise-matched
-                                       aggregates, Ad(S_v)-transported prolongation; single GPU),
-                                       -1 = automatic, in the well-posed arithmetic only: chain for
-                                       nearly pure chains (off-chain edges <= rows/64), multigrid for
-                                       >= 2000 free vertices with >= 8 off-diagonal blocks per row,
+                                       2 = aggregation multigrid (pairwise-matched aggregates,
+                                       Ad(S_v)-transported prolongation, dense coarsest level),
+                                       -1 = automatic, in the well-posed arithmetic only: multigrid
+                                       when the graph has more than 256 free vertices and coarsens
+                                       like a low-dimensional graph (level-1 blocks <= 0.3 x level-0
+                                       blocks: chains, chains with loops, Manhattan worlds -- not
+                                       expanders), chain segments for smaller nearly pure chains,
                                        else block-Jacobi                                           */
   int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */

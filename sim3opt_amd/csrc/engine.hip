@@ -1134,9 +1134,19 @@ class Engine {
     // (only in the well-posed arithmetic: as written, cond(H + lambda I) reaches 1e12 on KITTI, the
     // recursive residual of a strongly preconditioned CG drifts from the true one, and LM leaves
     // the exact-Cholesky trajectory at its second iteration -- measured)
-    use_chain = opt.preconditioner == 1 ||
-                (opt.preconditioner < 0 && comm.world == 1 && opt.fix_small_angle_b != 0 &&
-                 off_chain_edges <= std::max<int64_t>(2, nb / 64));
+    // Automatic choice (well-posed arithmetic only): the multigrid hierarchy whenever the graph
+    // coarsens like a low-dimensional one (level-1 blocks <= 0.3 x level-0 blocks: chains, KITTI
+    // with its loops, Manhattan worlds -- not expanders such as config 2, where block-Jacobi
+    // converges in tens of iterations); graphs too small for a hierarchy (<= 256 rows) get chain
+    // segments if they are nearly pure chains; block-Jacobi otherwise.
+    if (opt.preconditioner == 2 || (opt.preconditioner < 0 && opt.fix_small_angle_b != 0)) {
+      int rc = amg_init(s, opt.preconditioner < 0, err);
+      if (rc) return rc;
+    }
+    use_chain = !use_amg &&
+                (opt.preconditioner == 1 ||
+                 (opt.preconditioner < 0 && comm.world == 1 && opt.fix_small_angle_b != 0 &&
+                  off_chain_edges <= std::max<int64_t>(2, nb / 64)));
     chain_seg = std::max(2, std::min(opt.chain_segment > 0 ? opt.chain_segment : 256, CHAIN_SEG_MAX));
     if (use_chain) {
       std::vector<int32_t> sf(nb, -1), scnt(nb, 0);
@@ -1157,28 +1167,8 @@ class Engine {
       HIPCHK(hipMalloc((void**)v, sizeof(double) * n_alloc));
       HIPCHK(hipMemset(*v, 0, sizeof(double) * n_alloc));
     }
-    // multigrid for large loop-rich graphs (config 3: every vertex tied to ~20 neighbours), where
-    // block-Jacobi PCG needs thousands of iterations; same well-posedness condition as the chain
-    if (const char* ev = std::getenv("SIM3OPT_AMG_OMEGA")) amg_omega = std::max(0.1, std::min(0.95, std::atof(ev)));
-    // defaults (measured).  One GPU: additive on level 0 (one level-0 matrix pass per
-    // PCG iteration instead of three, about twice the iterations), level 1 once and deeper levels
-    // twice per visit.  Row-partitioned: multiplicative (half the iterations = half the collectives),
-    // deeper levels three times per visit.
-    amg_additive = comm.world == 1;
-    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = l <= 1 ? 1 : (amg_additive ? 2 : 3);
-    if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) {  // e.g. "122": visits of levels 1, 2, 3...
-      int last = 1;
-      for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
-        if ((int)std::strlen(ev) >= l && ev[l - 1] >= '1' && ev[l - 1] <= '3') last = ev[l - 1] - '0';
-        amg_visits[l] = last;
-      }
-    }
-    if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
-    const double avg_off = nb > 0 ? (double)(nnzb - nb) / nb : 0.0;
-    if (!use_chain &&
-        (opt.preconditioner == 2 ||
-         (opt.preconditioner < 0 && opt.fix_small_angle_b != 0 && nb >= 2000 && avg_off >= 8.0))) {
-      int rc = amg_init(s, err);
+    if (use_amg) {  // level 0 aliases the system's own arrays and vectors
+      int rc = amg_bind(s, err);
       if (rc) return rc;
     }
     HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * MAX_GRID));
@@ -1268,13 +1258,42 @@ class Engine {
 
   // structure of the hierarchy (once per initialize); leaves use_amg false when the graph does
   // not coarsen (block-Jacobi is used then)
-  int amg_init(const Structure& s, std::string& err) {
-    std::vector<AmgLevelHost> H;
+  std::vector<AmgLevelHost> amg_host;  // kept between amg_init and amg_bind
+  int amg_init(const Structure& s, bool automatic, std::string& err) {
+    (void)err;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_OMEGA")) amg_omega = std::max(0.1, std::min(0.95, std::atof(ev)));
+    // cycle (measured): multiplicative on level 0, level 1 once and deeper levels three
+    // times per visit; the additive level-0 form is a knob (about as fast on config 3, less robust
+    // on ill-conditioned chains)
+    amg_additive = false;
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = l <= 1 ? 1 : 3;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) {  // e.g. "122": visits of levels 1, 2, 3...
+      int last = 1;
+      for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
+        if ((int)std::strlen(ev) >= l && ev[l - 1] >= '1' && ev[l - 1] <= '3') last = ev[l - 1] - '0';
+        amg_visits[l] = last;
+      }
+    }
+    if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
     std::string why;
-    if (!build_amg_hierarchy(nb, s.rowptr.data(), s.colidx.data(), H, why)) {
-      if (opt.verbose) std::fprintf(stderr, "sim3opt: no multigrid hierarchy (%s): block-Jacobi\n", why.c_str());
+    if (!build_amg_hierarchy(nb, s.rowptr.data(), s.colidx.data(), amg_host, why)) {
+      if (opt.verbose) std::fprintf(stderr, "sim3opt: no multigrid hierarchy (%s)\n", why.c_str());
+      amg_host.clear();
       return SIM3OPT_OK;
     }
+    if (automatic && (double)amg_host[1].nnzb > 0.3 * (double)amg_host[0].nnzb) {
+      if (opt.verbose)
+        std::fprintf(stderr, "sim3opt: the graph coarsens like an expander (level-1 blocks %.2f of level 0): block-Jacobi\n",
+                     (double)amg_host[1].nnzb / (double)amg_host[0].nnzb);
+      amg_host.clear();
+      return SIM3OPT_OK;
+    }
+    use_amg = true;
+    return SIM3OPT_OK;
+  }
+
+  int amg_bind(const Structure& s, std::string& err) {
+    std::vector<AmgLevelHost>& H = amg_host;
     const int nl = (int)H.size();
     amg.assign(nl, AmgLevel());
     int rc = SIM3OPT_OK;
@@ -1326,7 +1345,8 @@ class Engine {
       for (const AmgLevel& L : amg) std::fprintf(stderr, " %d/%lld", L.nb, (long long)L.nnzb);
       std::fprintf(stderr, "\n");
     }
-    use_amg = true;
+    amg_host.clear();
+    amg_host.shrink_to_fit();
     amg_stale = true;
     return SIM3OPT_OK;
   }
