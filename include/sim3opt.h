@@ -244,6 +244,15 @@ int sim3opt_read_keyframe_bin(const char* path, int32_t* kf_id, double Rw2c[9], 
 int sim3opt_reanchor_points(int32_t n_frames, const double* old_Rt, const double* new_states,
                             int32_t n_points, double* points, int32_t n_obs,
                             const int32_t* obs_frame, const int32_t* obs_point, int32_t device);
+/* BAL problem file (ceres-solver format) handed from figureKITTIBA to ba_demo:
+ * SaveBALFile                                                          drawPTAMPoints.cpp:218-283
+ * Rw2c: n_cams x 9 row-major, tw2c: n_cams x 3, points: n_points x 3, observations as (camera,
+ * point, u, v).  Point ids must be exactly 0..n_points-1 (SIM3OPT_ERR_ARG otherwise; the reference
+ * exits).  Host only. */
+int sim3opt_write_bal(const char* path, int32_t n_cams, const double* Rw2c, const double* tw2c,
+                      const double f_k1_k2[3], int32_t n_points, const double* points,
+                      int32_t n_obs, const int32_t* obs_cam, const int32_t* obs_point,
+                      const double* obs_uv);
 /* g2o text export (VERTEX_SIM3:EXPMAP / EDGE_SIM3:EXPMAP / FIX) of a graph with ids 0..n-1 and
  * identity information, for re-running it in stock g2o */
 int sim3opt_write_g2o(sim3opt_graph* g, const char* path);

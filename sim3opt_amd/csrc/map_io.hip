@@ -9,6 +9,7 @@
 //       built here can be re-run in stock g2o (format from upstream g2o, not in the reference tree)
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -162,4 +163,50 @@ extern "C" int sim3opt_write_g2o(sim3opt_graph* g, const char* path) {
   }
   std::fclose(f);
   return SIM3OPT_OK;
+}
+
+// BAL problem file of figureKITTIBA's hand-off to ba_demo: SaveBALFile, drawPTAMPoints.cpp:218-283
+// (format of the ceres-solver BAL reader: "cams points obs", one "cam point u v" line per
+// observation, then 9 numbers per camera -- angle-axis of R_w2c, t_w2c, f, k1, k2 -- and 3 per point,
+// one per line, %.16g).  Like the reference, the camera frame stays right-down-forward and the
+// observations keep their principal point (drawPTAMPoints.cpp:214-215, :255).  Point ids must be
+// exactly 0..n_points-1 (the reference exits otherwise, :243-247; here: SIM3OPT_ERR_ARG).
+extern "C" int sim3opt_write_bal(const char* path, int32_t n_cams, const double* Rw2c,
+                                 const double* tw2c, const double f_k1_k2[3], int32_t n_points,
+                                 const double* points, int32_t n_obs, const int32_t* obs_cam,
+                                 const int32_t* obs_point, const double* obs_uv) {
+  if (!path || n_cams < 1 || n_points < 1 || n_obs < 1 || !Rw2c || !tw2c || !f_k1_k2 || !points ||
+      !obs_cam || !obs_point || !obs_uv)
+    return SIM3OPT_ERR_ARG;
+  int32_t lo = n_points, hi = -1;
+  for (int32_t j = 0; j < n_obs; ++j) {
+    if (obs_cam[j] < 0 || obs_cam[j] >= n_cams) return SIM3OPT_ERR_ARG;
+    lo = obs_point[j] < lo ? obs_point[j] : lo;
+    hi = obs_point[j] > hi ? obs_point[j] : hi;
+  }
+  if (lo != 0 || hi != n_points - 1) return SIM3OPT_ERR_ARG;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return SIM3OPT_ERR_IO;
+  std::fprintf(f, "%d %d %d\n", n_cams, n_points, n_obs);
+  for (int32_t j = 0; j < n_obs; ++j)
+    std::fprintf(f, "%d %d %g %g\n", obs_cam[j], obs_point[j], obs_uv[2 * (size_t)j],
+                 obs_uv[2 * (size_t)j + 1]);
+  for (int32_t c = 0; c < n_cams; ++c) {
+    double q[4];  // xyzw, w >= 0 (rotro2qr, drawPTAMPoints.cpp:204-211)
+    sim3::quat_from_R(Rw2c + 9 * (size_t)c, q);
+    if (q[3] < 0)
+      for (double& v : q) v = -v;
+    // quaternion -> angle-axis (ceres QuaternionToAngleAxis, called at drawPTAMPoints.cpp:256)
+    const double s2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    double k = 2.0;
+    if (s2 > 0.0) {
+      const double sn = std::sqrt(s2);
+      k = 2.0 * std::atan2(sn, q[3]) / sn;
+    }
+    const double cam[9] = {k * q[0], k * q[1], k * q[2], tw2c[3 * (size_t)c], tw2c[3 * (size_t)c + 1],
+                           tw2c[3 * (size_t)c + 2], f_k1_k2[0], f_k1_k2[1], f_k1_k2[2]};
+    for (double v : cam) std::fprintf(f, "%.16g\n", v);
+  }
+  for (size_t k = 0; k < 3 * (size_t)n_points; ++k) std::fprintf(f, "%.16g\n", points[k]);
+  return std::fclose(f) == 0 ? SIM3OPT_OK : SIM3OPT_ERR_IO;
 }

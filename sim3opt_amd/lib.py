@@ -119,6 +119,7 @@ SYMBOLS = {
     "sim3opt_reanchor_points": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip,
                                           C.c_int32]),
     "sim3opt_write_g2o": (C.c_int, [_vp, C.c_char_p]),
+    "sim3opt_write_bal": (C.c_int, [C.c_char_p, C.c_int32, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip, _dp]),
     "sim3opt_align_trajectory": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _dp]),
 }
 
@@ -470,6 +471,21 @@ def reanchor_points(old_Rt, new_states, points, obs_frame, obs_point, device=-1)
     if rc != OK:
         raise Sim3OptError(rc, "reanchor_points")
     return pts
+
+
+def write_bal(path, Rw2c, tw2c, f_k1_k2, points, obs_cam, obs_point, obs_uv):
+    """SaveBALFile (drawPTAMPoints.cpp:218-283): cameras (R_w2c row-major, t_w2c), points, observations."""
+    R = _f64(Rw2c).reshape(-1, 9)
+    t = _f64(tw2c).reshape(-1, 3)
+    fk = _f64(f_k1_k2).reshape(3)
+    pts = _f64(points).reshape(-1, 3)
+    oc, op = _i32(obs_cam), _i32(obs_point)
+    uv = _f64(obs_uv).reshape(-1, 2)
+    rc = load().sim3opt_write_bal(os.fsencode(path), R.shape[0], _p(R, _dp), _p(t, _dp), _p(fk, _dp),
+                                  pts.shape[0], _p(pts, _dp), oc.shape[0], _p(oc, _ip), _p(op, _ip),
+                                  _p(uv, _dp))
+    if rc != OK:
+        raise Sim3OptError(rc, "write_bal")
 
 
 def align_trajectory(query_xyz, train_xyz, with_scale=True):

@@ -98,3 +98,44 @@ def test_map_reanchoring_matches_sequential_restatement():
     # identity correction leaves the map where it was
     same = np.array([S3.make(S3.R_to_quat(k["Rw2c"]), k["twinc"], 1.0) for k in kfs])
     assert np.abs(L.reanchor_points(old_Rt, same, points, obs_f, obs_p) - points).max() < 1e-9
+
+
+def test_bal_writer_from_keyframes(tmp_path):
+    """SaveBALFile (drawPTAMPoints.cpp:218-283) on the three fixture keyframes, with the id
+    compaction of figureKITTIBA (:347-371): parse the file back and compare."""
+    frames = [L.read_keyframe_bin(os.path.join(KF_DIR, n)) for n in sorted(os.listdir(KF_DIR))]
+    allpts = {}
+    for d in frames:  # later keyframes overwrite a point's coordinates (:333-341)
+        for pid, p in zip(d["point_ids"], d["points_w"]):
+            allpts[int(pid)] = p
+    compact = {pid: k for k, pid in enumerate(sorted(allpts))}
+    points = np.array([allpts[pid] for pid in sorted(allpts)])
+    oc = np.concatenate([np.full(len(d["point_ids"]), c) for c, d in enumerate(frames)])
+    op = np.concatenate([[compact[int(p)] for p in d["point_ids"]] for d in frames])
+    uv = np.concatenate([d["obs_uv"] for d in frames])
+    R = np.array([d["Rw2c"] for d in frames])
+    t = np.array([d["twinc"] for d in frames])
+    path = str(tmp_path / "problem.txt")
+    L.write_bal(path, R, t, [718.856, 0, 0], points, oc, op, uv)
+    tok = open(path).read().split()
+    nc, npnt, no = int(tok[0]), int(tok[1]), int(tok[2])
+    assert (nc, npnt, no) == (3, len(points), len(oc))
+    o = 3
+    obs = np.array(tok[o:o + 4 * no], dtype=np.float64).reshape(no, 4); o += 4 * no
+    assert np.array_equal(obs[:, 0], oc) and np.array_equal(obs[:, 1], op)
+    assert np.abs(obs[:, 2:] - uv).max() < 5e-4 * np.abs(uv).max()  # %g: 6 significant digits
+    cams = np.array(tok[o:o + 9 * nc], dtype=np.float64).reshape(nc, 9); o += 9 * nc
+    for c in range(nc):  # Rodrigues of the angle-axis gives R_w2c back
+        w = cams[c, :3]
+        th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / max(th, 1e-300)
+        Rb = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        assert np.abs(Rb - R[c].reshape(3, 3)).max() < 1e-12
+        # (%.16g as in the reference: one digit short of a bit-exact round trip)
+        assert np.abs(cams[c, 3:6] - t[c]).max() <= 1e-15 * np.abs(t[c]).max() and list(cams[c, 6:]) == [718.856, 0, 0]
+    pts = np.array(tok[o:], dtype=np.float64).reshape(npnt, 3)
+    assert np.abs(pts - points).max() <= 1e-15 * np.abs(points).max()
+    with pytest.raises(L.Sim3OptError):  # point ids with a gap: the reference exits (:243-247)
+        L.write_bal(path, R, t, [718.856, 0, 0], points, oc, op + (op > 5), uv)
+    with pytest.raises(L.Sim3OptError):
+        L.write_bal(str(tmp_path / "no" / "dir.txt"), R, t, [1, 0, 0], points, oc, op, uv)
