@@ -501,6 +501,23 @@ def test_huber_and_information_lm():
     assert synth.rmse(G.get_vertices(), OG.states) < 1e-4
 
 
+def test_huber_and_information_lm_through_multigrid():
+    """Robust weights and dense information matrices only change the numbers of H: the multigrid
+    hierarchy (Galerkin products of whatever the linearisation wrote) must follow."""
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(400, 4000, dims=(6, 6, 10))
+    inf = spd_info(g["v0"].shape[0], 11)
+    G = mk(g, info=inf, kernel=L.KERNEL_HUBER, kdelta=0.5, fix_small_angle_b=1,
+           pcg_rel_tol=1e-12, fd_delta=1e-6)
+    assert G.preconditioner_in_use() == 2
+    OG = oracle_of(g, info=inf, kernel=1, kdelta=0.5)
+    G.optimize(6)
+    _, tr = OG.optimize(6, O.default_options(fix_small_angle_b=1, fd_delta=1e-6))
+    assert all(s.pcg_rel_res <= 1e-12 for s in G.stats())
+    assert abs(G.stats()[-1].chi2_after - tr[-1].chi2_after) < 1e-5 * tr[-1].chi2_after
+    assert synth.rmse(G.get_vertices(), OG.states) < 1e-4
+
+
 def test_determinism_and_warm_start():
     g = small(6)
     A = mk(g)
