@@ -123,19 +123,15 @@ __global__ __launch_bounds__(WG) void k_amg_wsum(int nc, const int32_t* __restri
   if (lane < 49) Wc[(size_t)49 * a + lane] = acc;
 }
 
-// r_c[a] = sum over members i of P_i^T t_f[i]; then x_c[a] = Minv_c[a] r_c[a] (first smoothing step
-// of the coarse level from a zero guess).  63 lanes = 9 aggregates x 7 entries.
-template <bool HASP>
+// Coarse levels (piecewise-constant prolongation): r_c[a] = sum over members i of t_f[i]; then
+// x_c[a] = Minv_c[a] r_c[a] (first smoothing step of the coarser level from a zero guess).
+// 63 lanes = 9 aggregates x 7 entries.
 __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __restrict__ mptr,
                                                      const int32_t* __restrict__ mem,
-                                                     const double* __restrict__ P,
                                                      const double* __restrict__ t_f,
                                                      double* __restrict__ r_c,
                                                      const double* __restrict__ Minv_c,
-                                                     double* __restrict__ x_c,
-                                                     const DevScalars* __restrict__ sc, int row_lo,
-                                                     int row_hi) {
-  if (sc && sc->done) return;
+                                                     double* __restrict__ x_c) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
@@ -144,21 +140,7 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
     const bool act = lane < 63 && a < nc;
     const int e0 = act ? mptr[a] : 0, e1 = act ? mptr[a + 1] : 0;
     double acc = 0.0;
-    for (int e = e0; __any(e < e1); ++e) {
-      const int i = e < e1 ? mem[e] : 0;
-      // multi-GPU: a rank sums the members it owns; the partial sums are all-reduced afterwards
-      const bool on = e < e1 && i >= row_lo && i < row_hi;
-      const double tv = on ? t_f[(size_t)7 * i + rr] : 0.0;
-      if (HASP) {
-#pragma unroll
-        for (int m = 0; m < 7; ++m) {
-          const double tm = __shfl(tv, base + m);
-          if (on) acc += P[(size_t)49 * i + m + 7 * rr] * tm;
-        }
-      } else {
-        acc += tv;
-      }
-    }
+    for (int e = e0; e < e1; ++e) acc += t_f[(size_t)7 * mem[e] + rr];
     if (act) r_c[(size_t)7 * a + rr] = acc;
     if (Minv_c) {
       double xv = 0.0;

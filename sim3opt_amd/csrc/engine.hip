@@ -1441,9 +1441,8 @@ class Engine {
                          F.mem, d_P, t, Cc.r, split ? (const double*)nullptr : Minv_c, Cc.x,
                          (const DevScalars*)d_sc, r0, r1);
     else
-      hipLaunchKernelGGL((k_amg_restrict<false>), dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
-                         (const double*)nullptr, t, Cc.r, Minv_c, Cc.x, (const DevScalars*)nullptr, 0,
-                         F.nb);
+      hipLaunchKernelGGL(k_amg_restrict, dim3(gr), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem, t, Cc.r,
+                         Minv_c, Cc.x);
     if (split) {
       if (amg_status == SIM3OPT_OK) amg_status = comm.allreduce(Cc.r, 7 * Cc.nb, 0, stream, amg_err);
       if (Minv_c)
