@@ -13,7 +13,7 @@ G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8, time_kernels=1, preconditione
 t = time.time(); G.add_vertices(g["states"], g["fixed"]); G.add_edges(g["v0"], g["v1"], g["meas"]); G.initialize(); print("host build + upload %.1fs" % (time.time() - t), flush=True)
 nb, nnzb = G.system_dims()
 chi0 = G.chi2()
-t = time.time(); n = G.optimize(4); dt = time.time() - t
+t = time.time(); n = G.optimize(int(os.environ.get("NIT", "4"))); dt = time.time() - t
 st = G.stats(); kt = G.kernel_times()
 byt = nnzb * 396 + (nb + 1) * 4 + 3 * 7 * nb * 8
 out = dict(vertices=V, edges=E, preconditioner=G.preconditioner_in_use(), pcg_rel_res=[s.pcg_rel_res for s in st], ms_solve=[s.ms_solve for s in st], blocks=nnzb, vals_GB=nnzb * 392 / 1e9, lm_iters=n, seconds=dt, lm_iters_per_s=n / dt, edges_iters_per_s=E * n / dt,
