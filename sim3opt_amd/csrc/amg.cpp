@@ -149,7 +149,9 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
     std::vector<int32_t> agg(nb);
     std::iota(agg.begin(), agg.end(), 0);
     int32_t nc = nb;
-    int npass = 3;
+    // aggregates of 8 (3 passes); graphs small enough for two levels with aggregates of 4 take those:
+    // on KITTI-00 (770 rows -> 192 dense) a third of the PCG iterations (measured)
+    int npass = levels.size() == 1 && nb <= 4 * max_coarsest ? 2 : 3;
     if (const char* ev = std::getenv("SIM3OPT_AMG_PASSES")) {  // tuning knob: passes per level, e.g. "344"
       const size_t l = std::min(levels.size() - 1, std::strlen(ev) - 1);
       if (std::strlen(ev) > 0 && ev[l] >= '1' && ev[l] <= '6') npass = ev[l] - '0';
