@@ -230,3 +230,19 @@ def test_amg_hierarchy_structure():
     with pytest.raises(L.Sim3OptError) as ei:
         S.amg_hierarchy()
     assert ei.value.code == L.ERR_STATE
+
+
+def test_amg_hierarchy_on_the_kitti_fixture():
+    """The 771-keyframe chain coarsens to a two-level hierarchy with aggregates of 4 consecutive
+    keyframes (770 -> 192 rows, block-tridiagonal coarse pattern); the 117 extra loop edges change
+    a few aggregates, not the shape.  Pins the aggregation against silent changes."""
+    G = L.Graph()
+    G.load_kitti_direct(K.FIXTURE, True)
+    rows, blocks, agg = G.amg_hierarchy()
+    assert list(rows) == [770, 192] and list(blocks) == [2310, 576]
+    assert list(agg[:770]) == [i // 4 for i in range(768)] + [191, 191]
+    G = L.Graph()
+    G.load_kitti_direct(K.FIXTURE, False)
+    rows, blocks, agg = G.amg_hierarchy()
+    assert list(rows) == [770, 191] and list(blocks) == [2544, 641]
+    assert np.bincount(agg[:770]).max() <= 8
