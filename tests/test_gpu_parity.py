@@ -307,6 +307,18 @@ def test_pcg_reports_breakdown_on_indefinite_system():
     G.linearize()
     with pytest.raises(L.Sim3OptError):
         G.solve(-1e12)
+    # through the multigrid path: its set-up meets non-positive pivots, the solve falls back to
+    # block-Jacobi, which reports the breakdown; the next (definite) solve is unaffected
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(400, 4000, dims=(6, 6, 10))
+    G = mk(g, fix_small_angle_b=1, pcg_rel_tol=1e-10)
+    assert G.preconditioner_in_use() == 2
+    G.linearize()
+    x0, it0, _ = G.solve(1.0)
+    with pytest.raises(L.Sim3OptError):
+        G.solve(-1e12)
+    x1, it1, rr = G.solve(1.0)
+    assert it1 == it0 and rr <= 1e-10 and np.array_equal(x0, x1)
 
 
 # ------------------------------------------------------------------ Levenberg-Marquardt
