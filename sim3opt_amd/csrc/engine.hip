@@ -48,6 +48,7 @@ using sim3::Sim3;
 constexpr int WG = 256;         // 4 wavefronts of 64
 constexpr int PCG_GRAPH_ITERS = 16;  // PCG iterations per captured hipGraph (even: parity returns)
 constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
+constexpr int SPAN_GRID_MAX = 6144;  // workgroups of the span SpMV (its partials: one pair each)
                                 // (256 CUs x 8 workgroups of 4 waves = full occupancy)
 
 // Scalars that live in HBM so the PCG loop needs no host round trip per iteration.
@@ -1104,9 +1105,13 @@ class Engine {
     HIPCHK(upload(d_incptr, s.incptr));
     {  // span SpMV: contiguous row span per wavefront, balanced by stored blocks
       const int nloc = r1 - r0;
-      int span_cap = 2048;  // 256 CUs x 8 workgroups of 4 wavefronts: all resident at once
-      if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) span_cap = std::max(8, std::min(MAX_GRID, std::atoi(ev)));  // tuning knob (no effect measured)
-      span_grid = std::max(8, std::min(span_cap, (nloc + 15) / 16));
+      // 3x the resident set (256 CUs x 8 workgroups of 4 wavefronts): shorter spans make the
+      // addresses in flight a window that moves through the matrix instead of 8192 streams spread
+      // over all of it (measured: 2048 -> 0.172 ms, 4096 -> 0.164, 6144 -> 0.1626, 8192 -> 0.1627,
+      // 16384 -> 0.179 on config 3); small systems get one block row per wavefront
+      int span_cap = SPAN_GRID_MAX;
+      if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) span_cap = std::max(8, std::min(SPAN_GRID_MAX, std::atoi(ev)));  // tuning knob
+      span_grid = std::max(8, std::min(span_cap, (nloc + 3) / 4));
       const int nw = span_grid * 4;
       std::vector<int32_t> wrow(nw + 1);
       partition_rows(nloc, s.rowptr.data() + r0, nw, wrow.data());
@@ -1171,8 +1176,8 @@ class Engine {
       int rc = amg_bind(s, err);
       if (rc) return rc;
     }
-    HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * MAX_GRID));
-    HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * MAX_GRID));
+    HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * SPAN_GRID_MAX));
+    HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * SPAN_GRID_MAX));
     HIPCHK(hipMalloc((void**)&d_sc, sizeof(DevScalars)));
     HIPCHK(hipMemset(d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipHostMalloc((void**)&h_sc, sizeof(DevScalars)));
@@ -1640,7 +1645,10 @@ class Engine {
     const int gv = grid_for((nloc + 8) / 9, 4);  // 36 block rows per workgroup pass
     const int gs = spmv_grid();
     const bool multi = comm.active();
-    const double* scal = multi ? &d_sc->tmp_pq : nullptr;  // [w.z, r.z] after the all-reduce
+    // [w.z, r.z] summed once by k_final_sum2 (multi-GPU: then all-reduced) instead of by every
+    // workgroup of the PCG step when the SpMV leaves more partials than a workgroup sums for free
+    const bool pre_sum = multi || gs > MAX_GRID;
+    const double* scal = pre_sum ? &d_sc->tmp_pq : nullptr;
     // automatic cap: small systems may need ~n iterations for an (almost) exact step like the
     // reference's Cholesky (chains are ill-conditioned); large ones get a truncated-Newton budget
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters
@@ -1724,8 +1732,11 @@ class Engine {
       HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       for (int c = 0; c < graph_iters; ++c) {
         spmv_raw(lambda, zin, d_q, d_r, d_sc);
+        if (pre_sum)
+          hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
+                             &d_sc->tmp_pq);
         hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(WG), 0, stream, r0, r1, (1 + c) & 1, -1,
-                           (const double*)nullptr, d_part_a, d_part_b, gs, Minv_arg,
+                           scal, d_part_a, d_part_b, gs, Minv_arg,
                            (const double*)zin, d_z, d_q, d_p, d_s, d_x, d_r, d_sc);
         if (use_chain)
           hipLaunchKernelGGL(k_chain_apply, dim3(gc), dim3(WG), 0, stream, r0, r1, chain_seg,
@@ -1759,9 +1770,10 @@ class Engine {
       for (int c = 0; c < todo; ++c) {
         rc = spmv_launch(lambda, zin, err);
         if (rc) return rc;
-        if (multi) {  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent), one 2-double all-reduce
+        if (pre_sum)  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent)
           hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
                              &d_sc->tmp_pq);
+        if (multi) {  // one 2-double all-reduce
           rc = comm.allreduce(&d_sc->tmp_pq, 2, 0, stream, err);
           if (rc) return rc;
         }
