@@ -48,7 +48,7 @@ using sim3::Sim3;
 constexpr int WG = 256;         // 4 wavefronts of 64
 constexpr int PCG_GRAPH_ITERS = 16;  // PCG iterations per captured hipGraph (even: parity returns)
 constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
-constexpr int SPAN_GRID_MAX = 6144;  // workgroups of the span SpMV (its partials: one pair each)
+constexpr int SPAN_GRID_MAX = 65536;  // workgroups of the span SpMV (its partials: one pair each)
                                 // (256 CUs x 8 workgroups of 4 waves = full occupancy)
 
 // Scalars that live in HBM so the PCG loop needs no host round trip per iteration.
@@ -1109,9 +1109,11 @@ class Engine {
       // addresses in flight a window that moves through the matrix instead of 8192 streams spread
       // over all of it (measured: 2048 -> 0.172 ms, 4096 -> 0.164, 6144 -> 0.1626, 8192 -> 0.1627,
       // 16384 -> 0.179 on config 3); small systems get one block row per wavefront
-      int span_cap = SPAN_GRID_MAX;
-      if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) span_cap = std::max(8, std::min(SPAN_GRID_MAX, std::atoi(ev)));  // tuning knob
-      span_grid = std::max(8, std::min(span_cap, (nloc + 3) / 4));
+      // rule: ~4 block rows per wavefront (16 per workgroup), but never fewer workgroups than the
+      // resident set as long as every wavefront still gets a row
+      span_grid = std::max(std::min(2048, (nloc + 3) / 4), (nloc + 15) / 16);
+      if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) span_grid = std::min(std::atoi(ev), (nloc + 3) / 4);  // tuning knob
+      span_grid = std::max(8, std::min(SPAN_GRID_MAX, span_grid));
       const int nw = span_grid * 4;
       std::vector<int32_t> wrow(nw + 1);
       partition_rows(nloc, s.rowptr.data() + r0, nw, wrow.data());
