@@ -9,11 +9,12 @@ from sim3opt_amd import lib as L, synth
 synth.DRIFT_TARGET = 0.05
 g = synth.manhattan()
 res = {}
-variants = ["1024", "2048", "3072", "4096", "1536"]
+KNOB = os.environ.get("KNOB", "SIM3OPT_SPAN_GRID")
+variants = os.environ.get("VARIANTS", "2048,4096,6250,8192").split(";") if KNOB != "SIM3OPT_SPAN_GRID" else os.environ.get("VARIANTS", "2048,4096,6250,8192").split(",")
 for rep in range(2):
     for v in variants:
-        os.environ["SIM3OPT_SPAN_GRID"] = v
-        G = L.Graph(fix_small_angle_b=1); G.add_vertices(g['states'], g['fixed']); G.add_edges(g['v0'], g['v1'], g['meas']); G.initialize()
+        os.environ[KNOB] = v
+        G = L.Graph(fix_small_angle_b=1, preconditioner=0); G.add_vertices(g['states'], g['fixed']); G.add_edges(g['v0'], g['v1'], g['meas']); G.initialize()
         G.linearize()
         nb, nnzb = G.system_dims()
         ms = G.bench_spmv(50)
