@@ -113,7 +113,7 @@ int add_edge_impl(sim3opt_graph* g, int32_t id0, int32_t id1, const double* meas
 
 extern "C" {
 
-int sim3opt_version(void) { return 100; }
+int sim3opt_version(void) { return 110; }  // 1.1: multigrid preconditioner, hierarchy / BAL entry points
 
 void sim3opt_options_default(sim3opt_options* o) {
   if (!o) return;
