@@ -500,8 +500,11 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   double pq = 0.0, pr = 0.0;
   // per-row operands are requested when the row starts and consumed when it ends
   double pi_n = 0.0, rv_n = 0.0, mv = 0.0;
-  auto row_begin = [&](int row) {
-    pi_n = p[(size_t)7 * row + r];
+  // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
+  // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
+  // instruction per row; the kernel is bound by the number of those, not by their bytes)
+  auto row_begin = [&](int row, int u, double xg) {
+    pi_n = __shfl(xg, 7 * u + r);
     if (rvec) rv_n = rvec[(size_t)7 * row + r];
     if (MODE == 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
   };
@@ -538,7 +541,6 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
     int rbase = rA;
     int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
     int row = rA;
-    row_begin(row);
     int k1 = __builtin_amdgcn_readlane(rpv, 0);
     // column indices, 64 blocks at a time, one per lane; window w covers [kbeg + 64 w, +64)
     int cbase = kbeg;
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
       const int colu = __shfl(cv, kk - cbase);
       xgc = p[(size_t)7 * colu + gc];
     }
+    row_begin(row, 0, xgc);
     for (int k = kbeg; k < kend; k += CH) {
       const int kn = k + CH;
       if (kn < kend) {  // issue the next chunk before consuming this one
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
             row_end(row, acc);
             acc = 0.0;
             ++row;
-            row_begin(row);
+            row_begin(row, u, xgc);
             if (row - rbase >= 64) {
               rbase += 64;
               rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
