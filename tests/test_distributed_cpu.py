@@ -26,6 +26,17 @@ def _free_port():
     return p
 
 
+def _spawn(fn, world, out):
+    """mp.spawn with one retry on a fresh port (a rendezvous on a just-released port can lose a race)."""
+    for attempt in (0, 1):
+        try:
+            mp.spawn(fn, args=(world, _free_port(), out), nprocs=world, join=True)
+            return
+        except Exception:
+            if attempt == 1:
+                raise
+
+
 def _block_system(seed=0):
     from oracle import oracle as O
     from sim3opt_amd import synth
@@ -99,8 +110,7 @@ def _worker(rank, world, port, out):
 
 def test_partitioned_pcg_over_gloo_matches_serial(tmp_path):
     out = str(tmp_path / "x.npy")
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    _spawn(_worker, 2, out)
     x = np.load(out)
     H, b = _block_system()
     lam = 1e-5 * np.abs(np.diag(H)).max()
@@ -245,7 +255,7 @@ def _amg_worker(rank, world, port, out):
 
 def test_partitioned_multigrid_pcg_over_gloo_matches_serial(tmp_path):
     out = str(tmp_path / "amg.npz")
-    mp.spawn(_amg_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    _spawn(_amg_worker, 2, out)
     res = np.load(out)
     H, b, P = _amg_system()
     n = H.shape[0]
