@@ -64,7 +64,13 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
     products and restricted residuals, replicated coarse levels)."""
     from sim3opt_amd import lib as L, synth
     out = str(tmp_path / "r")
-    mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True)
+    for attempt in (0, 1):  # one retry on a fresh port (a rendezvous on a just-released port can lose a race)
+        try:
+            mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
     res = [np.load(out + f".{r}.npz") for r in range(world)]
     g = _graph(prec)
     if prec == 2:  # the single-GPU default cycle is the additive one; compare like with like
