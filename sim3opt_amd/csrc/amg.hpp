@@ -6,7 +6,8 @@
 // VertexSim3Expmap::oplusImpl uses, that is dx_v = Ad(S_v) g).  Block-Jacobi cannot see them, so on
 // locally connected graphs (Manhattan world: every vertex linked to ~20 neighbours a few cells
 // away) PCG needs thousands of iterations.  The hierarchy here coarsens the GRAPH by pairwise
-// matching (3 passes = aggregates of up to 8 block rows per level); the numbers (Galerkin products
+// matching (3 passes = aggregates of 8 block rows per level, 2 passes when that already reaches the
+// dense level); the numbers (Galerkin products
 // with the Ad-transported piecewise-constant prolongation) are formed on the GPU after every
 // linearisation (engine.hip / amg_kernels.hpp).  The reference solves the system exactly
 // (LinearSolverEigen, kitti_surf.cpp:553-554); this is how the PCG gets to the same answer in tens

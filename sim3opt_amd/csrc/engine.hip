@@ -6,7 +6,9 @@
 //   BaseBinaryEdge::linearizeOplus (numeric)   -> k_linearize_numeric (lane = one +-delta evaluation)
 //   BaseBinaryEdge::constructQuadraticForm     -> k_linearize_numeric (Gram phase) + k_diag_reduce
 //   BlockSolverX::buildSystem / setLambda      -> block-CSR values in HBM; lambda folded into SpMV
-//   LinearSolverEigen::solve (SimplicialLDLT)  -> block-Jacobi PCG: k_jacobi, k_spmv, k_pcg_*
+//   LinearSolverEigen::solve (SimplicialLDLT)  -> preconditioned CG: k_spmv_span, k_pcg_*; block-Jacobi
+//                                                 (k_jacobi), chain segments (k_chain_*) or aggregation
+//                                                 multigrid (amg.cpp, amg_kernels.hpp, Engine::amg_*)
 //   VertexSim3Expmap::oplusImpl, push/pop      -> k_oplus + device-to-device backup copies
 //   OptimizationAlgorithmLevenberg::solve      -> Engine::optimize (host control, 3 scalars per trial)
 //
@@ -16,6 +18,8 @@
 //   vals     nnzb x 49, column-major 7x7 blocks, block row = free vertex, diagonal block first
 //   scratch  (#incidences) x 35: per (edge, endpoint) upper triangle of J^T W J (28) and -J^T W e (7)
 //   PCG vectors x r z p q b: 7*nb each; Minv nb x 49 row-major
+//   multigrid   P nb x 49 (Ad(S_v)), per coarse level its own block-CSR + diagH/W/Minv + 3 vectors,
+//               dense inverse of the coarsest level (two n x n buffers, n <= 1792)
 // Assembly is atomic-free and reduction orders are fixed, so results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
