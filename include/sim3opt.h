@@ -61,7 +61,8 @@ typedef struct sim3opt_options {
                                         the scale+translation stage, kitti_surf.cpp:1020-1024)    */
   int32_t pcg_max_iters;    /* 0 = automatic: 2n for n = 7*free vertices <= 50000, else 1000 */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
-  int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls      */
+  int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls (at most 4 with the
+                                        multigrid preconditioner: its iterations are ~1 ms each)  */
   int32_t pcg_graph;        /* 1     replay the PCG iterations from a captured hipGraph (single GPU,
                                         time_kernels = 0); 0 = enqueue every launch               */
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
