@@ -472,6 +472,9 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 // MODE 0: q = A p (+ the dot partials; the PCG's SpMV).  The multigrid preconditioner reuses the
 // same stream for its two matrix passes per level: MODE 1: q = rvec - A p (residual),
 // MODE 2: q = p + Minv (rvec - A p) (one damped block-Jacobi step; Minv = omega D^-1, row-major).
+// MODE 3 (coarse multigrid levels): MODE 2 applied to p + xc[agg] -- the piecewise-constant
+// prolongation of the coarser level's correction is added while the input vector is gathered
+// (xc through `partials_r`, which the non-PCG modes do not use).
 template <int CH, bool NT, int MODE>
 __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
                                                   const double* __restrict__ rvec,
                                                   double* __restrict__ partials_r,
                                                   DevScalars* __restrict__ sc,
-                                                  const double* __restrict__ Minv, int lam_sc) {
+                                                  const double* __restrict__ Minv, int lam_sc,
+                                                  const int32_t* __restrict__ agg) {
   __shared__ double sh[4];
   if (sc) {
     if (sc->done) return;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
   auto row_begin = [&](int row, int u, double xg) {
     pi_n = __shfl(xg, 7 * u + r);
     if (rvec) rv_n = rvec[(size_t)7 * row + r];
-    if (MODE == 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
+    if (MODE >= 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
   };
   // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
   // (row sums are valid in lanes 0..6)
@@ -564,6 +568,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
       const int kk = kbeg + gu < kend ? kbeg + gu : kend - 1;
       const int colu = __shfl(cv, kk - cbase);
       xgc = p[(size_t)7 * colu + gc];
+      if (MODE == 3) xgc += partials_r[(size_t)7 * agg[colu] + gc];
     }
     row_begin(row, 0, xgc);
     for (int k = kbeg; k < kend; k += CH) {
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
         const int kk = kn + gu < kend ? kn + gu : kend - 1;
         const int colu = __shfl(cv, kk - cbase);
         xgn = p[(size_t)7 * colu + gc];
+        if (MODE == 3) xgn += partials_r[(size_t)7 * agg[colu] + gc];
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
@@ -1429,8 +1435,9 @@ class Engine {
     }  // the inverse is in d_Ainv
   }
 
+  // mode 3 (coarse levels): mode 2 on v + xc[agg], the coarser level's correction prolonged on the fly
   void spmv_mode(const AmgLevel& L, int mode, int level, const double* v, double* out,
-                 const double* rvec) {
+                 const double* rvec, const double* xc = nullptr) {
     // level 0 carries the damping as a scalar (read from DevScalars: capturable); coarse levels
     // have it inside their diagonal blocks.  Level 0 streams once (non-temporal), the rest is small.
     // Only level-0 launches test the `done` flag: on the latency-bound coarse levels that dependent
@@ -1438,9 +1445,10 @@ class Engine {
 #define AMG_SPMV(NTV, MODEV)                                                                     \
   hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
                      L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, (double*)nullptr, rvec,     \
-                     (double*)nullptr, level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1)
+                     const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
+                     (const int32_t*)L.agg)
     if (level == 0) { if (mode == 1) AMG_SPMV(true, 1); else AMG_SPMV(true, 2); }
-    else { if (mode == 1) AMG_SPMV(false, 1); else AMG_SPMV(false, 2); }
+    else { if (mode == 1) AMG_SPMV(false, 1); else if (mode == 3) AMG_SPMV(false, 3); else AMG_SPMV(false, 2); }
 #undef AMG_SPMV
   }
 
@@ -1502,8 +1510,12 @@ class Engine {
     spmv_mode(F, 1, l, cur, other, F.r);
     amg_restrict(l, other);
     const double* xc = amg_coarse(l);
-    amg_prolong(l, xc, cur, cur);
-    spmv_mode(F, 2, l, cur, other, F.r);
+    if (l == 0) {
+      amg_prolong(l, xc, cur, cur);
+      spmv_mode(F, 2, l, cur, other, F.r);
+    } else {  // piecewise-constant prolongation: added while the smoothing pass gathers its input
+      spmv_mode(F, 3, l, cur, other, F.r, xc);
+    }
     return other;
   }
 
@@ -1595,11 +1607,11 @@ class Engine {
 #define SPAN_CASE(CH, NTV)                                                                       \
   hipExtLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb, \
                         d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,         \
-                        d_part_b, scp, (const double*)nullptr, 1)
+                        d_part_b, scp, (const double*)nullptr, 1, (const int32_t*)nullptr)
 #define SPAN_PLAIN(CH, NTV)                                                                     \
   hipLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, nb, d_wrow,       \
                      d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp,     \
-                     (const double*)nullptr, 1)
+                     (const double*)nullptr, 1, (const int32_t*)nullptr)
     if (!ev0) {  // plain launch: capturable into a hipGraph
       if (spmv_chunk <= 4) { if (spmv_nt) SPAN_PLAIN(4, true); else SPAN_PLAIN(4, false); }
       else { if (spmv_nt) SPAN_PLAIN(8, true); else SPAN_PLAIN(8, false); }
