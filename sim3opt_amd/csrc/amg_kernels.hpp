@@ -269,44 +269,56 @@ __global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __
 // A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS.
 __global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int kb, const double* __restrict__ A,
                                                           double* __restrict__ B, DevScalars* sc) {
-  __shared__ double P[7][7];
+  __shared__ double P[7][8];
+  __shared__ double ak[7][64];    // pivot rows A_k. for the tile's columns
   __shared__ double rowk[7][64];  // (P A_k.) for the tile's columns
-  __shared__ double colk[64][7];  // A_.k for the tile's rows
-  const int tid = threadIdx.x;
+  __shared__ double colk[64][8];  // A_.k for the tile's rows
+  const int tid = threadIdx.x, lane = tid & 63;
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64, k0 = 7 * kb;
-  if (tid == 0) {
-    double a[7][7];
-    for (int r = 0; r < 7; ++r)
-      for (int c = 0; c < 7; ++c) a[r][c] = A[(size_t)(k0 + r) * n + k0 + c];
-    bool spd = true;
-    for (int k = 0; k < 7; ++k) {
-      if (!(a[k][k] > 0.0)) spd = false;
-      const double d = 1.0 / a[k][k];
-      for (int j = 0; j < 7; ++j)
-        if (j != k) a[k][j] *= d;
-      for (int i = 0; i < 7; ++i)
-        if (i != k) {
-          const double f = a[i][k];
-          for (int j = 0; j < 7; ++j)
-            if (j != k) a[i][j] -= f * a[k][j];
-          a[i][k] = -f * d;
-        }
-      a[k][k] = d;
-    }
-    for (int r = 0; r < 7; ++r)
-      for (int c = 0; c < 7; ++c) P[r][c] = a[r][c];
-    if (!spd && blockIdx.x == 0 && blockIdx.y == 0) sc->fail = 1;
+  // every global read of the set-up is issued before anything waits: one memory round trip
+  double prow[7];  // wavefront 0: lane i < 7 holds row i of the pivot block
+  if (tid < 64) {
+    const int rr = lane < 7 ? lane : 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) prow[c] = A[(size_t)(k0 + rr) * n + k0 + c];
   }
-  for (int t = tid; t < 64 * 7; t += WG) {  // A_.k slice
+  for (int t = tid; t < 64 * 7; t += WG) {
     const int i = t / 7, m = t % 7;
     colk[i][m] = i0 + i < n ? A[(size_t)(i0 + i) * n + k0 + m] : 0.0;
+  }
+  for (int t = tid; t < 7 * 64; t += WG) {
+    const int q = t / 64, j = t % 64;
+    ak[q][j] = j0 + j < n ? A[(size_t)(k0 + q) * n + j0 + j] : 0.0;
+  }
+  if (tid < 64) {  // in-place Gauss-Jordan inverse of the 7x7 pivot block: rows in lanes, no barrier
+    bool spd = true;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      double pk[7];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) pk[c] = __shfl(prow[c], k);
+      if (!(pk[k] > 0.0)) spd = false;
+      const double d = 1.0 / pk[k];
+      const double f = prow[k];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const double rk = pk[j] * d;  // scaled pivot row
+        if (lane == k) prow[j] = j == k ? d : rk;
+        else prow[j] = j == k ? -f * d : prow[j] - f * rk;
+      }
+    }
+    if (lane < 7) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) P[lane][c] = prow[c];
+    }
+    if (!spd && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) sc->fail = 1;
   }
   __syncthreads();
   for (int t = tid; t < 7 * 64; t += WG) {  // (P A_k.) slice
     const int m = t / 64, j = t % 64;
     double acc = 0.0;
-    if (j0 + j < n)
-      for (int q = 0; q < 7; ++q) acc += P[m][q] * A[(size_t)(k0 + q) * n + j0 + j];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc += P[m][q] * ak[q][j];
     rowk[m][j] = acc;
   }
   __syncthreads();
