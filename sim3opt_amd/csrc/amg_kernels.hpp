@@ -262,70 +262,73 @@ __global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __
   }
 }
 
-// ... inverted by Gauss-Jordan with 7x7 block pivots and no pivot search (SPD: positive pivots),
-// one launch per block pivot, out of place (B = step_k(A), buffers ping-pong) so that no workgroup
-// reads what another one overwrites:
+// ... inverted by block Gauss-Jordan without pivot search (SPD: positive pivots), one launch per
+// pivot block of PB = 14 rows (a last one of 7 when the row count is odd; every launch costs ~13 us
+// whatever its work, so half the launches is half the time), out of place (B = step(A), buffers
+// ping-pong) so that no workgroup reads what another one overwrites:
 //   P = A_kk^-1;  B_kk = P;  B_kj = P A_kj;  B_ik = -A_ik P;  B_ij = A_ij - A_ik (P A_kj)
-// A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS.
-__global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int kb, const double* __restrict__ A,
+// A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS; its first
+// wavefront inverts the pivot block with one row per lane (shuffles, no barrier).
+template <int PB>
+__global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int k0, const double* __restrict__ A,
                                                           double* __restrict__ B, DevScalars* sc) {
-  __shared__ double P[7][8];
-  __shared__ double ak[7][64];    // pivot rows A_k. for the tile's columns
-  __shared__ double rowk[7][64];  // (P A_k.) for the tile's columns
-  __shared__ double colk[64][8];  // A_.k for the tile's rows
+  __shared__ double P[PB][PB + 1];
+  __shared__ double ak[PB][64];       // pivot rows A_k. for the tile's columns
+  __shared__ double rowk[PB][64];     // (P A_k.) for the tile's columns
+  __shared__ double colk[64][PB + 1]; // A_.k for the tile's rows
   const int tid = threadIdx.x, lane = tid & 63;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64, k0 = 7 * kb;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   // every global read of the set-up is issued before anything waits: one memory round trip
-  double prow[7];  // wavefront 0: lane i < 7 holds row i of the pivot block
+  double prow[PB];  // wavefront 0: lane i < PB holds row i of the pivot block
   if (tid < 64) {
-    const int rr = lane < 7 ? lane : 0;
+    const int rr = lane < PB ? lane : 0;
 #pragma unroll
-    for (int c = 0; c < 7; ++c) prow[c] = A[(size_t)(k0 + rr) * n + k0 + c];
+    for (int c = 0; c < PB; ++c) prow[c] = A[(size_t)(k0 + rr) * n + k0 + c];
   }
-  for (int t = tid; t < 64 * 7; t += WG) {
-    const int i = t / 7, m = t % 7;
+  for (int t = tid; t < 64 * PB; t += WG) {
+    const int i = t / PB, m = t % PB;
     colk[i][m] = i0 + i < n ? A[(size_t)(i0 + i) * n + k0 + m] : 0.0;
   }
-  for (int t = tid; t < 7 * 64; t += WG) {
+  for (int t = tid; t < PB * 64; t += WG) {
     const int q = t / 64, j = t % 64;
     ak[q][j] = j0 + j < n ? A[(size_t)(k0 + q) * n + j0 + j] : 0.0;
   }
-  if (tid < 64) {  // in-place Gauss-Jordan inverse of the 7x7 pivot block: rows in lanes, no barrier
+  if (tid < 64) {  // in-place Gauss-Jordan inverse of the pivot block
     bool spd = true;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      double pk[7];
+    for (int k = 0; k < PB; ++k) {
+      double pk[PB];
 #pragma unroll
-      for (int c = 0; c < 7; ++c) pk[c] = __shfl(prow[c], k);
+      for (int c = 0; c < PB; ++c) pk[c] = __shfl(prow[c], k);
       if (!(pk[k] > 0.0)) spd = false;
       const double d = 1.0 / pk[k];
       const double f = prow[k];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
+      for (int j = 0; j < PB; ++j) {
         const double rk = pk[j] * d;  // scaled pivot row
         if (lane == k) prow[j] = j == k ? d : rk;
         else prow[j] = j == k ? -f * d : prow[j] - f * rk;
       }
     }
-    if (lane < 7) {
+    if (lane < PB) {
 #pragma unroll
-      for (int c = 0; c < 7; ++c) P[lane][c] = prow[c];
+      for (int c = 0; c < PB; ++c) P[lane][c] = prow[c];
     }
     if (!spd && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) sc->fail = 1;
   }
   __syncthreads();
-  for (int t = tid; t < 7 * 64; t += WG) {  // (P A_k.) slice
+  for (int t = tid; t < PB * 64; t += WG) {  // (P A_k.) slice
     const int m = t / 64, j = t % 64;
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) acc += P[m][q] * ak[q][j];
+    for (int q = 0; q < PB; ++q) acc += P[m][q] * ak[q][j];
     rowk[m][j] = acc;
   }
   __syncthreads();
   for (int t = tid; t < 64 * 64; t += WG) {
     const int il = t / 64, jl = t % 64, i = i0 + il, j = j0 + jl;
     if (i >= n || j >= n) continue;
-    const bool ik = i >= k0 && i < k0 + 7, jk = j >= k0 && j < k0 + 7;
+    const bool ik = i >= k0 && i < k0 + PB, jk = j >= k0 && j < k0 + PB;
     double v;
     if (ik && jk) {
       v = P[i - k0][j - k0];
@@ -333,10 +336,12 @@ __global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int kb, const d
       v = rowk[i - k0][jl];
     } else if (jk) {
       v = 0.0;
-      for (int m = 0; m < 7; ++m) v -= colk[il][m] * P[m][j - k0];
+#pragma unroll
+      for (int m = 0; m < PB; ++m) v -= colk[il][m] * P[m][j - k0];
     } else {
       v = A[(size_t)i * n + j];
-      for (int m = 0; m < 7; ++m) v -= colk[il][m] * rowk[m][jl];
+#pragma unroll
+      for (int m = 0; m < PB; ++m) v -= colk[il][m] * rowk[m][jl];
     }
     B[(size_t)i * n + j] = v;
   }

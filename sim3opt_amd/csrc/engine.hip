@@ -1415,22 +1415,27 @@ class Engine {
                          L.rowptr, L.vals, lambda, L.Minv, d_sc, l == 0 && amg_additive ? 1.0 : amg_omega,
                          L.diagH, L.W);
     }
-    // dense inverse of the coarsest level: one launch per 7x7 block pivot, buffers ping-pong
+    // dense inverse of the coarsest level: one launch per 14-row pivot block, buffers ping-pong
     const AmgLevel& Lc = amg[nl - 1];
     const int nd = 7 * Lc.nb;
     (void)hipMemsetAsync(d_Ainv2, 0, sizeof(double) * (size_t)nd * nd, stream);
     hipLaunchKernelGGL(k_amg_dense_fill, dim3(grid_for(49 * Lc.nnzb, WG)), dim3(WG), 0, stream, Lc.nb,
                        Lc.rowptr, Lc.colidx, Lc.vals, d_Ainv2);
+    const int nsteps = (Lc.nb + 1) / 2;  // 14-row pivot blocks, a last one of 7 rows when nb is odd
     double *src = d_Ainv2, *dst = d_Ainv;
-    if (Lc.nb % 2 == 0) {  // an even number of steps would end in d_Ainv2: start from d_Ainv instead
+    if (nsteps % 2 == 0) {  // an even number of steps would end in d_Ainv2: start from d_Ainv instead
       (void)hipMemcpyAsync(d_Ainv, d_Ainv2, sizeof(double) * (size_t)nd * nd, hipMemcpyDeviceToDevice, stream);
       src = d_Ainv;
       dst = d_Ainv2;
     }
     const dim3 gt((nd + 63) / 64, (nd + 63) / 64);
-    for (int kb = 0; kb < Lc.nb; ++kb) {
-      hipLaunchKernelGGL(k_amg_dense_gj_step, gt, dim3(WG), 0, stream, nd, kb, (const double*)src, dst,
-                         d_sc);
+    for (int k0 = 0; k0 < nd; k0 += 14) {
+      if (nd - k0 >= 14)
+        hipLaunchKernelGGL((k_amg_dense_gj_step<14>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
+                           dst, d_sc);
+      else
+        hipLaunchKernelGGL((k_amg_dense_gj_step<7>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
+                           dst, d_sc);
       std::swap(src, dst);
     }  // the inverse is in d_Ainv
   }
