@@ -94,9 +94,16 @@ __device__ __forceinline__ double block_sum(double v, double* sh4) {
 }
 
 __device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n, double* sh4) {
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += WG) acc += p[i];
-  return block_sum(acc, sh4);
+  // (four loads in flight per thread: with thousands of partials the plain loop was a chain of
+  // load-wait-add round trips)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * WG < n; i += 4 * WG) {
+    const double v0 = p[i], v1 = p[i + WG], v2 = p[i + 2 * WG], v3 = p[i + 3 * WG];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; i < n; i += WG) a0 += p[i];
+  return block_sum((a0 + a1) + (a2 + a3), sh4);
 }
 
 __global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ partials, int n,
