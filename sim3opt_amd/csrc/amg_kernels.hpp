@@ -140,7 +140,14 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
     const bool act = lane < 63 && a < nc;
     const int e0 = act ? mptr[a] : 0, e1 = act ? mptr[a + 1] : 0;
     double acc = 0.0;
-    for (int e = e0; e < e1; ++e) acc += t_f[(size_t)7 * mem[e] + rr];
+    int e = e0;
+    for (; e + 3 < e1; e += 4) {  // four members in flight
+      const int i0 = mem[e], i1 = mem[e + 1], i2 = mem[e + 2], i3 = mem[e + 3];
+      const double v0 = t_f[(size_t)7 * i0 + rr], v1 = t_f[(size_t)7 * i1 + rr];
+      const double v2 = t_f[(size_t)7 * i2 + rr], v3 = t_f[(size_t)7 * i3 + rr];
+      acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; e < e1; ++e) acc += t_f[(size_t)7 * mem[e] + rr];
     if (act) r_c[(size_t)7 * a + rr] = acc;
     if (Minv_c) {
       double xv = 0.0;
@@ -356,8 +363,15 @@ __global__ __launch_bounds__(WG) void k_amg_dense_apply(int n, const double* __r
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
-    double acc = 0.0;
-    for (int j = lane; j < n; j += 64) acc += Ainv[(size_t)i * n + j] * r[j];
+    const double* row = Ainv + (size_t)i * n;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four loads in flight per lane
+    int j = lane;
+    for (; j + 192 < n; j += 256) {
+      const double m0 = row[j], m1 = row[j + 64], m2 = row[j + 128], m3 = row[j + 192];
+      a0 += m0 * r[j]; a1 += m1 * r[j + 64]; a2 += m2 * r[j + 128]; a3 += m3 * r[j + 192];
+    }
+    for (; j < n; j += 64) a0 += row[j] * r[j];
+    double acc = (a0 + a1) + (a2 + a3);
     acc = wave_sum(acc);
     if (lane == 0) x[i] = acc;
   }
