@@ -79,6 +79,15 @@ typedef struct sim3opt_options {
   int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */
   int32_t time_kernels;     /* 0     1: bracket every SpMV / linearise launch with HIP events
                                         (sim3opt_get_kernel_times); small launch-gap cost    */
+  int32_t linear_solver;    /* -1    how (H + lambda I) dx = b is solved (LinearSolverEigen's role,
+                                        kitti_surf.cpp:553-554):
+                                        1 = exact sparse block Cholesky on the GPU (nested-dissection
+                                            order, level-scheduled; the reference's SimplicialLDLT),
+                                        0 = preconditioned CG (see `preconditioner`),
+                                       -1 = automatic: the exact factorisation when it is cheap (single
+                                            GPU, at most ~3e5 7x7x7 block products per factorisation:
+                                            KITTI-00 and other chain-like graphs) and no
+                                            `preconditioner` was named, else the PCG                */
 } sim3opt_options;
 
 /* Per-iteration record (g2o G2OBatchStatistics role; bal_example.cpp:55-56). */
@@ -170,6 +179,11 @@ int sim3opt_edge_errors(sim3opt_graph* g, double* e_out);
 int sim3opt_linearize(sim3opt_graph* g);
 /* dimensions of the block-CSR system: free block rows, stored 7x7 blocks */
 int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks);
+/* the block-CSR pattern alone (host only, no GPU needed, may be called before initialize): two
+ * calls, arrays NULL to size them.  Row k = k-th free vertex in insertion order: its diagonal block,
+ * then one block per incident edge whose other endpoint is free, sorted by (column, edge). */
+int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks,
+                           int32_t* rowptr, int32_t* colidx);
 /* copies the block-CSR Hessian (rowptr nb+1, colidx nnzb, values nnzb x 49 column-major per
  * block) and b (7 nb) to the host; block row k = k-th free vertex in insertion order */
 int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
@@ -185,6 +199,22 @@ int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* m
 /* Preconditioner the PCG of this (initialized) graph uses: 0 block-Jacobi, 1 chain segments,
  * 2 aggregation multigrid (what `preconditioner = -1` resolved to); negative = error code. */
 int sim3opt_preconditioner_in_use(const sim3opt_graph* g);
+/* Linear solver of this (initialized) graph: 1 exact sparse block Cholesky, 0 PCG (what
+ * `linear_solver = -1` resolved to); negative = error code. */
+int sim3opt_linear_solver_in_use(const sim3opt_graph* g);
+/* Plan of the exact sparse block Cholesky (LinearSolverEigen's role, kitti_surf.cpp:553-554) for this
+ * graph: host only, no GPU needed, may be called before initialize.  Block column j of L is block row
+ * perm[j] of the system (nested-dissection order); its stored 7x7 blocks are colptr[j]..colptr[j+1]
+ * (diagonal first, rows lrow[] ascending).  Block s of L starts from the sum of the system's blocks
+ * src[srcptr[s]..srcptr[s+1]) (indices into the block-CSR values of sim3opt_get_system) and subtracts
+ * L[pa[k]] L[pb[k]]^T for k in pairptr[s]..pairptr[s+1].  Schedule: group q runs levels
+ * gptr[q]..gptr[q+1], level l is columns lcolp[l]..lcolp[l+1]; groups but the last are independent.
+ * dims = {columns, blocks of L, block products per factorisation, elimination-tree height, groups,
+ * levels, entries of src, 0}.  Two calls: arrays NULL to size them, then filled.  max_pairs <= 0: the
+ * automatic limit.  SIM3OPT_ERR_STATE when a factorisation needs more block products than that. */
+int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], int32_t* perm,
+                        int32_t* colptr, int32_t* lrow, int32_t* srcptr, int32_t* src,
+                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp);
 /* Structure of the multigrid hierarchy `preconditioner = 2` would use for this graph (host only, no
  * GPU needed, may be called before initialize): *n_levels levels; rows[l] / blocks[l] = block rows
  * and stored 7x7 blocks of level l (up to `capacity` levels are written); aggregate_of_row (may be

@@ -1,6 +1,6 @@
 """GPU A/B of the PCG preconditioners on Manhattan graphs: block-Jacobi (0) vs aggregation
 multigrid (2).  One linear solve at two dampings (solutions compared), then LM runs.
-Usage: python scripts/gpu_amg_test.py [small|full]"""
+Usage: python scripts/gpu_amg_run.py [small|full]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

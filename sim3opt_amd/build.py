@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsim3opt.so")
-SOURCES = ["engine.hip", "capi.cpp", "graph.cpp", "kitti_io.cpp", "comm.cpp", "eval.cpp", "stepwise.cpp", "map_io.hip", "amg.cpp"]
-HEADERS = ["engine.hpp", "graph.hpp", "comm.hpp", "sim3_math.hpp", "amg.hpp", "amg_kernels.hpp", os.path.join("..", "..", "include", "sim3opt.h")]
+SOURCES = ["engine.hip", "capi.cpp", "graph.cpp", "kitti_io.cpp", "comm.cpp", "eval.cpp", "stepwise.cpp", "map_io.hip", "amg.cpp", "direct.cpp"]
+HEADERS = ["engine.hpp", "graph.hpp", "comm.hpp", "sim3_math.hpp", "amg.hpp", "amg_kernels.hpp", "direct.hpp", "direct_kernels.hpp", os.path.join("..", "..", "include", "sim3opt.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-result"]

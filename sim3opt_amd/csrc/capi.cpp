@@ -11,6 +11,7 @@
 #include "../../include/sim3opt.h"
 #include "amg.hpp"
 #include "comm.hpp"
+#include "direct.hpp"
 #include "engine.hpp"
 #include "graph.hpp"
 
@@ -136,6 +137,7 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->device = -1;
   o->verbose = 0;
   o->time_kernels = 0;
+  o->linear_solver = -1;
 }
 
 sim3opt_graph* sim3opt_create(void) {
@@ -351,6 +353,18 @@ int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* 
   return SIM3OPT_OK;
 }
 
+int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks,
+                           int32_t* rowptr, int32_t* colidx) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  Structure st;
+  if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
+  if (n_block_rows) *n_block_rows = st.nb;
+  if (n_blocks) *n_blocks = st.nnzb;
+  if (rowptr) std::memcpy(rowptr, st.rowptr.data(), sizeof(int32_t) * (size_t)(st.nb + 1));
+  if (colidx) std::memcpy(colidx, st.colidx.data(), sizeof(int32_t) * (size_t)st.nnzb);
+  return SIM3OPT_OK;
+}
+
 int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
                        double* b) {
   if (!g) return SIM3OPT_ERR_ARG;
@@ -374,6 +388,35 @@ int sim3opt_preconditioner_in_use(const sim3opt_graph* g) {
   if (!g) return SIM3OPT_ERR_ARG;
   if (!g->initialized) return SIM3OPT_ERR_STATE;
   return engine_preconditioner(g->engine);
+}
+
+int sim3opt_linear_solver_in_use(const sim3opt_graph* g) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return SIM3OPT_ERR_STATE;
+  return engine_linear_solver(g->engine);
+}
+
+int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], int32_t* perm,
+                        int32_t* colptr, int32_t* lrow, int32_t* srcptr, int32_t* src,
+                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp) {
+  if (!g || !dims) return fail(g, SIM3OPT_ERR_ARG, "direct_plan: bad argument");
+  Structure st;
+  if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
+  DirectPlan P;
+  std::string why;
+  if (!build_direct_plan(st.nb, st.rowptr.data(), st.colidx.data(), max_pairs > 0 ? max_pairs : 300000, 0,
+                         P, why)) {
+    g->err = "direct_plan: " + why;
+    return SIM3OPT_ERR_STATE;
+  }
+  dims[0] = P.nb; dims[1] = P.nL; dims[2] = P.npairs; dims[3] = P.height; dims[4] = P.ngroups();
+  dims[5] = (int64_t)P.lcolp.size() - 1; dims[6] = (int64_t)P.src.size(); dims[7] = 0;
+  auto out = [](int32_t* dst, const std::vector<int32_t>& v) {
+    if (dst && !v.empty()) std::memcpy(dst, v.data(), sizeof(int32_t) * v.size());
+  };
+  out(perm, P.perm); out(colptr, P.colptr); out(lrow, P.lrow); out(srcptr, P.srcptr); out(src, P.src);
+  out(pairptr, P.pairptr); out(pa, P.pa); out(pb, P.pb); out(gptr, P.gptr); out(lcolp, P.lcolp);
+  return SIM3OPT_OK;
 }
 
 int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels, int32_t* rows,

@@ -34,6 +34,7 @@
 
 #include "amg.hpp"
 #include "comm.hpp"
+#include "direct.hpp"
 #include "engine.hpp"
 
 namespace sim3opt {
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 }
 
 #include "amg_kernels.hpp"
+#include "direct_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
@@ -890,11 +892,14 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
 // update and scale
 // ------------------------------------------------------------------------------------------
 // VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
+// (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
+// fact; the step is then garbage and must not be applied -- the host rejects the trial)
 __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
                                               const double* __restrict__ x, Sim3* states,
-                                              sim3::Opts opts) {
+                                              sim3::Opts opts, const DevScalars* sc) {
   const int v = blockIdx.x * WG + threadIdx.x;
   if (v >= nv) return;
+  if (sc && sc->fail) return;
   const int h = hidx[v];
   if (h < 0) return;
   double xi[7];
@@ -1018,6 +1023,16 @@ class Engine {
   bool amg_additive = false;           // level 0 additive: no fine-level matrix pass in the cycle
   int amg_status = 0;                  // first collective error inside a cycle
   std::string amg_err;
+  // exact sparse block Cholesky (direct.hpp, direct_kernels.hpp): LinearSolverEigen's role on
+  // graphs whose factorisation is cheap (KITTI-00 and other chain-like graphs)
+  DirectPlan dplan;
+  bool use_direct = false;
+  LdlArgs ldl{};
+  int ldl_wg_sub = LDL_WG_SUB;
+  std::vector<void*> direct_owned;
+  // chi2 of the current estimates when it is already known (the last accepted trial computed it)
+  bool chi_known = false;
+  double chi_cache = 0.0;
   // hipGraph of `graph_iters` PCG iterations (single GPU, untimed runs): replayed per chunk
   hipGraphExec_t pcg_graph = nullptr;
   int pcg_graph_kind = -1;
@@ -1048,6 +1063,9 @@ class Engine {
     for (void* p : amg_owned)
       if (p) (void)hipFree(p);
     amg_owned.clear();
+    for (void* p : direct_owned)
+      if (p) (void)hipFree(p);
+    direct_owned.clear();
     if (h_sc) (void)hipHostFree(h_sc);
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -1166,11 +1184,17 @@ class Engine {
     // with its loops, Manhattan worlds -- not expanders such as config 2, where block-Jacobi
     // converges in tens of iterations); graphs too small for a hierarchy (<= 256 rows) get chain
     // segments if they are nearly pure chains; block-Jacobi otherwise.
-    if (opt.preconditioner == 2 || (opt.preconditioner < 0 && opt.fix_small_angle_b != 0)) {
+    // (naming a preconditioner asks for the PCG)
+    if (opt.linear_solver == 1 || (opt.linear_solver < 0 && opt.preconditioner < 0)) {
+      int rc = direct_init(s, err);
+      if (rc) return rc;
+    }
+    if (!use_direct &&
+        (opt.preconditioner == 2 || (opt.preconditioner < 0 && opt.fix_small_angle_b != 0))) {
       int rc = amg_init(s, opt.preconditioner < 0, err);
       if (rc) return rc;
     }
-    use_chain = !use_amg &&
+    use_chain = !use_amg && !use_direct &&
                 (opt.preconditioner == 1 ||
                  (opt.preconditioner < 0 && comm.world == 1 && opt.fix_small_angle_b != 0 &&
                   off_chain_edges <= std::max<int64_t>(2, nb / 64)));
@@ -1557,6 +1581,97 @@ class Engine {
     return SIM3OPT_OK;
   }
 
+  // ---- exact sparse block Cholesky ----
+  template <typename T>
+  int direct_up(const T*& dptr, const std::vector<T>& h, std::string& err) {
+    T* p = nullptr;
+    HIPCHK(hipMalloc((void**)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    direct_owned.push_back(p);
+    if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    dptr = p;
+    return SIM3OPT_OK;
+  }
+  int direct_alloc(double*& dptr, size_t count, std::string& err) {
+    HIPCHK(hipMalloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
+    direct_owned.push_back(dptr);
+    HIPCHK(hipMemset(dptr, 0, sizeof(double) * std::max<size_t>(count, 1)));
+    return SIM3OPT_OK;
+  }
+
+  // plan (host, once per initialize) + buffers; leaves use_direct false when the factorisation
+  // would be too expensive (the PCG takes over) unless the caller insists
+  int direct_init(const Structure& s, std::string& err) {
+    const bool forced = opt.linear_solver == 1;
+    if (comm.world > 1) {
+      if (forced) {
+        err = "linear_solver = 1: the exact factorisation runs on one GPU (small graphs are not sharded)";
+        return SIM3OPT_ERR_ARG;
+      }
+      return SIM3OPT_OK;
+    }
+    // automatic: only where a factorisation costs less than a few PCG iterations would
+    int64_t max_pairs = forced ? 30000000 : 300000;
+    int32_t subtree = 0;
+    if (const char* ev = std::getenv("SIM3OPT_DIRECT_MAX_PAIRS")) max_pairs = std::atoll(ev);  // tuning knobs
+    if (const char* ev = std::getenv("SIM3OPT_DIRECT_SUBTREE")) subtree = std::atoi(ev);
+    if (const char* ev = std::getenv("SIM3OPT_DIRECT_WG_SUB")) ldl_wg_sub = std::max(64, std::min(1024, std::atoi(ev) / 64 * 64));
+    if (!forced && nb > 60000) return SIM3OPT_OK;
+    std::string why;
+    if (!build_direct_plan(nb, s.rowptr.data(), s.colidx.data(), max_pairs, subtree, dplan, why)) {
+      dplan = DirectPlan();
+      if (forced) {
+        err = "linear_solver = 1: " + why;
+        return SIM3OPT_ERR_ARG;
+      }
+      if (opt.verbose) std::fprintf(stderr, "sim3opt: no exact factorisation (%s): PCG\n", why.c_str());
+      return SIM3OPT_OK;
+    }
+    int rc = SIM3OPT_OK;
+#define DCHK(call) do { rc = (call); if (rc) return rc; } while (0)
+    DCHK(direct_up(ldl.perm, dplan.perm, err));
+    DCHK(direct_up(ldl.colptr, dplan.colptr, err));
+    DCHK(direct_up(ldl.lrow, dplan.lrow, err));
+    DCHK(direct_up(ldl.lcol, dplan.lcol, err));
+    DCHK(direct_up(ldl.srcptr, dplan.srcptr, err));
+    DCHK(direct_up(ldl.src, dplan.src, err));
+    DCHK(direct_up(ldl.pairptr, dplan.pairptr, err));
+    DCHK(direct_up(ldl.pa, dplan.pa, err));
+    DCHK(direct_up(ldl.pb, dplan.pb, err));
+    DCHK(direct_up(ldl.gptr, dplan.gptr, err));
+    DCHK(direct_up(ldl.lcolp, dplan.lcolp, err));
+    DCHK(direct_alloc(ldl.L, (size_t)49 * dplan.nL, err));
+    DCHK(direct_alloc(ldl.Dinv, (size_t)49 * nb, err));
+    DCHK(direct_alloc(ldl.y, (size_t)7 * nb, err));
+    DCHK(direct_alloc(ldl.xp, (size_t)7 * nb, err));
+#undef DCHK
+    if (opt.verbose)
+      std::fprintf(stderr,
+                   "sim3opt: exact block Cholesky: %d columns, %lld blocks in L, %lld block products, "
+                   "tree height %d, %d groups\n",
+                   nb, (long long)dplan.nL, (long long)dplan.npairs, dplan.height, dplan.ngroups());
+    use_direct = true;
+    return SIM3OPT_OK;
+  }
+
+  // (H + lambda I) x = b, exactly; x in d_x.  A non-positive pivot raises d_sc->fail (read by the
+  // caller together with the trial's chi2: no extra round trip).
+  int direct_solve(double lambda, std::string& err) {
+    HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
+    ldl.vals = d_vals;
+    ldl.b = d_b;
+    ldl.x = d_x;
+    ldl.sc = d_sc;
+    ldl.lambda = lambda;
+    const int ng = dplan.ngroups();
+    if (ng > 1)
+      hipLaunchKernelGGL((k_ldl<true, false>), dim3(ng - 1), dim3(ldl_wg_sub), 0, stream, ldl, 0);
+    hipLaunchKernelGGL((k_ldl<true, true>), dim3(1), dim3(LDL_WG_TOP), 0, stream, ldl, ng - 1);
+    if (ng > 1)
+      hipLaunchKernelGGL((k_ldl<false, true>), dim3(ng - 1), dim3(ldl_wg_sub), 0, stream, ldl, 0);
+    HIPCHK(hipGetLastError());
+    return SIM3OPT_OK;
+  }
+
   // ---- building blocks ----
   int chi2(double* out, std::string& err) {
     const int g = grid_for(e_hi - e_lo, WG);
@@ -1657,6 +1772,12 @@ class Engine {
   }
 
   int pcg(double lambda, int32_t* iters, double* rel_res, bool* ok, std::string& err) {
+    if (use_direct) {  // exact step; `ok` is settled later from d_sc->fail (see optimize)
+      *iters = 0;
+      *rel_res = 0.0;
+      *ok = true;
+      return direct_solve(lambda, err);
+    }
     if (use_amg || use_chain) {
       // the block-tridiagonal factorisation (or the multigrid's coarsest-level inverse) can meet a
       // non-positive pivot when H is numerically semi-definite (cond ~1e12 in the reference's
@@ -1850,13 +1971,20 @@ class Engine {
     double lambda = 0.0, ni = 2.0;
     bool ok = true;
     int iters = 0;
+    chi_known = false;  // (options or estimates may have changed since the last call)
     for (int it = 0; it < max_iters && ok; ++it) {
       sim3opt_iter_stats T{};
       double currentChi = 0.0;
       int rc = timed_begin(err);
       if (rc) return rc;
-      rc = chi2(&currentChi, err);
-      if (rc) return rc;
+      // computeActiveErrors at the start of an iteration: the estimates are those the last trial
+      // evaluated (accepted) or restored (rejected), and the evaluation is deterministic, so the
+      // value is already here -- one host round trip less per iteration
+      if (chi_known) currentChi = chi_cache;
+      else {
+        rc = chi2(&currentChi, err);
+        if (rc) return rc;
+      }
       double tempChi = currentChi;
       T.chi2_before = currentChi;
       rc = linearize(err);
@@ -1893,17 +2021,21 @@ class Engine {
         double scale = 0.0;
         if (ok2) {
           hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
-                             d_x, d_states, mopts());
+                             d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr);
           const int ge = grid_for(7 * (int64_t)(r1 - r0), WG);
           hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
                              lambda, d_part_b);
           hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, ge,
                              &d_sc->scale);
           HIPCHK(hipGetLastError());
-          rc = chi2(&tempChi, err);  // also brings back scale
+          rc = chi2(&tempChi, err);  // also brings back scale (and the factorisation's verdict)
           if (rc) return rc;
           scale = h_sc->scale;
           kt.n_update += 1;
+          if (use_direct && h_sc->fail) {  // not positive definite: g2o's solver returns false
+            tempChi = DBL_MAX;
+            scale = 0.0;
+          }
         } else {
           tempChi = DBL_MAX;  // solver failed: g2o forces rejection
         }
@@ -1927,6 +2059,8 @@ class Engine {
         ++qmax;
       } while (rho < 0 && qmax < opt.max_trials);
       kt.ms_update += T.ms_update;
+      chi_known = true;
+      chi_cache = currentChi;
       T.chi2_after = currentChi;
       T.lambda = lambda;
       T.rho = rho;
@@ -1996,6 +2130,7 @@ int engine_set_states(Engine* e, const Sim3* in, std::string& err) {
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->d_states, in, sizeof(Sim3) * (size_t)e->nv, hipMemcpyHostToDevice));
   e->linearized = false;
+  e->chi_known = false;
   return SIM3OPT_OK;
 }
 
@@ -2052,6 +2187,11 @@ int engine_solve(Engine* e, double lambda, double* x, int32_t* iters, double* re
   bool ok = true;
   int rc = e->pcg(lambda, &it, &rr, &ok, err);
   if (rc) return rc;
+  if (e->use_direct) {  // the factorisation reports a non-positive pivot through the scalars
+    rc = e->fetch_scalars(err);
+    if (rc) return rc;
+    ok = !e->h_sc->fail;
+  }
   if (iters) *iters = it;
   if (rel_res) *rel_res = rr;
   if (x) HIPCHK(hipMemcpy(x, e->d_x, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost));
@@ -2106,6 +2246,8 @@ void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end) {
 }
 
 int engine_preconditioner(const Engine* e) { return e->use_amg ? 2 : (e->use_chain ? 1 : 0); }
+
+int engine_linear_solver(const Engine* e) { return e->use_direct ? 1 : 0; }
 
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {
   if (out) *out = e->kt;

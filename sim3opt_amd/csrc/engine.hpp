@@ -40,6 +40,7 @@ int engine_solve(Engine* e, double lambda, double* x, int32_t* iters, double* re
 int engine_bench_spmv(Engine* e, int32_t reps, double* ms_mean, std::string& err);
 int engine_bench_stream(Engine* e, int32_t mode, int32_t reps, double* ms_mean, std::string& err);
 int engine_preconditioner(const Engine* e);
+int engine_linear_solver(const Engine* e);
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset);
 
 }  // namespace sim3opt

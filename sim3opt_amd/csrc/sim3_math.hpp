@@ -20,6 +20,20 @@
 #define S3_HD inline
 #endif
 
+// The reference differentiates numerically with delta = 1e-9 (g2o BaseBinaryEdge): a last-bit
+// difference in a residual becomes 1e-7 in a Jacobian entry, and the as-written B coefficient
+// (w_coeffs below) amplifies that further.  To stay as close to a CPU evaluation of the same formulae
+// as the hardware allows, every function here (a) performs its operations in the order a plain
+// C / Eigen statement of sim3_rv.h performs them (matrix products for Omega^2, partially pivoted LU
+// for W^-1 t, like TooN::LU at sim3_rv.h:305-307 and Eigen's lu().solve in g2o) and (b) forbids
+// fusing a*b+c into one rounding (x86-64 code of the reference's era has no FMA).  What is left
+// between this code on gfx950 and the CPU oracle is the last bit of sin/cos/acos/exp/log.
+#if defined(__clang__)
+#define S3_STRICT_FP _Pragma("clang fp contract(off)")
+#else
+#define S3_STRICT_FP
+#endif
+
 namespace sim3 {
 
 // 8 doubles = 64 bytes = half a 128-B HBM line; vertex states and edge
@@ -38,6 +52,7 @@ struct Opts {
 };
 
 S3_HD void quat_from_R(const double R[9], double q[4]) {
+  S3_STRICT_FP
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0) {
     double t = sqrt(tr + 1.0);
@@ -71,6 +86,7 @@ S3_HD void quat_from_R(const double R[9], double q[4]) {
 }
 
 S3_HD void R_from_quat(const double q[4], double R[9]) {
+  S3_STRICT_FP
   const double x = q[0], y = q[1], z = q[2], w = q[3];
   const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
   const double twx = tx * w, twy = ty * w, twz = tz * w;
@@ -82,6 +98,7 @@ S3_HD void R_from_quat(const double q[4], double R[9]) {
 }
 
 S3_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+  S3_STRICT_FP
   const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
   const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
   o[0] = aw * bx + ax * bw + ay * bz - az * by;
@@ -91,6 +108,7 @@ S3_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
 }
 
 S3_HD void quat_rot(const double q[4], const double v[3], double o[3]) {
+  S3_STRICT_FP
   const double ux = 2 * (q[1] * v[2] - q[2] * v[1]);
   const double uy = 2 * (q[2] * v[0] - q[0] * v[2]);
   const double uz = 2 * (q[0] * v[1] - q[1] * v[0]);
@@ -101,6 +119,7 @@ S3_HD void quat_rot(const double q[4], const double v[3], double o[3]) {
 
 // a * b : x -> a(b(x))                                   (sim3_rv.h:214-220)
 S3_HD Sim3 mul(const Sim3& a, const Sim3& b) {
+  S3_STRICT_FP
   Sim3 r;
   double rt[3];
   quat_mul(a.q, b.q, r.q);
@@ -113,6 +132,7 @@ S3_HD Sim3 mul(const Sim3& a, const Sim3& b) {
 }
 
 S3_HD Sim3 inverse(const Sim3& a) {                     // sim3_rv.h:199-203
+  S3_STRICT_FP
   Sim3 r;
   r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
   const double k = -1.0 / a.s;
@@ -125,6 +145,7 @@ S3_HD Sim3 inverse(const Sim3& a) {                     // sim3_rv.h:199-203
 // A, B, C of W = A*Omega + B*Omega^2 + C*I            (sim3_rv.h:143-181, :261-303)
 S3_HD void w_coeffs(double sigma, double s, double theta, bool small_theta, double eps, int fixb,
                     double& A, double& B, double& C) {
+  S3_STRICT_FP
   if (fabs(sigma) < eps) {
     C = 1.0;
     if (small_theta) {
@@ -153,66 +174,106 @@ S3_HD void w_coeffs(double sigma, double s, double theta, bool small_theta, doub
   }
 }
 
-// Omega = [w]x and Omega^2 = w w^T - |w|^2 I are formed in closed form;
-// W = A*Omega + B*Omega^2 + C*I, row-major.
-S3_HD void w_matrix(const double w[3], double A, double B, double C, double W[9]) {
-  const double xx = w[0] * w[0], yy = w[1] * w[1], zz = w[2] * w[2];
-  const double xy = w[0] * w[1], xz = w[0] * w[2], yz = w[1] * w[2];
-  W[0] = C - B * (yy + zz); W[1] = B * xy - A * w[2]; W[2] = B * xz + A * w[1];
-  W[3] = B * xy + A * w[2]; W[4] = C - B * (xx + zz); W[5] = B * yz - A * w[0];
-  W[6] = B * xz - A * w[1]; W[7] = B * yz + A * w[0]; W[8] = C - B * (xx + yy);
+// Omega = [w]x (sim3_rv.h:38-50) and Omega^2 by the matrix product, row-major
+S3_HD void skew_and_square(const double w[3], double Om[9], double Om2[9]) {
+  S3_STRICT_FP
+  Om[0] = 0;     Om[1] = -w[2]; Om[2] = w[1];
+  Om[3] = w[2];  Om[4] = 0;     Om[5] = -w[0];
+  Om[6] = -w[1]; Om[7] = w[0];  Om[8] = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += Om[3 * i + k] * Om[3 * k + j];
+      Om2[3 * i + j] = acc;
+    }
 }
 
 // Sim3(Vector7) of g2o                                    (sim3_rv.h:125-190)
 S3_HD Sim3 exp(const double xi[7], const Opts& o) {
+  S3_STRICT_FP
   const double* om = xi;
   const double sigma = xi[6];
   const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  double Om[9], Om2[9], R[9], W[9];
+  skew_and_square(om, Om, Om2);
   const double s = ::exp(sigma);
   const bool small = theta < o.eps;
   double A, B, C;
   w_coeffs(sigma, s, theta, small, o.eps, o.fix_small_b, A, B, C);
-  double k1, k2;
   if (small) {
-    k1 = 1.0;
-    k2 = o.small_rot_half ? 0.5 : 1.0;
+    const double h = o.small_rot_half ? 0.5 : 1.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Om[i] + h * Om2[i];
   } else {
-    k1 = sin(theta) / theta;
-    k2 = (1 - cos(theta)) / (theta * theta);
+    const double k1 = sin(theta) / theta, k2 = (1 - cos(theta)) / (theta * theta);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = k1 * Om[i] + k2 * Om2[i];
   }
-  double R[9], W[9];
-  w_matrix(om, k1, k2, 1.0, R);
-  w_matrix(om, A, B, C, W);
+  R[0] += 1; R[4] += 1; R[8] += 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = A * Om[i] + B * Om2[i];
+  W[0] += C; W[4] += C; W[8] += C;
   Sim3 r;
-  r.t[0] = W[0] * xi[3] + W[1] * xi[4] + W[2] * xi[5];
-  r.t[1] = W[3] * xi[3] + W[4] * xi[4] + W[5] * xi[5];
-  r.t[2] = W[6] * xi[3] + W[7] * xi[4] + W[8] * xi[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.t[i] = W[3 * i] * xi[3] + W[3 * i + 1] * xi[4] + W[3 * i + 2] * xi[5];
   quat_from_R(R, r.q);
   r.s = s;
   return r;
 }
 
-// 3x3 solve W x = t by the adjugate (W = C*I + small terms is well conditioned
-// wherever log is; replaces the LU of sim3_rv.h:305-307)
-S3_HD void solve33(const double W[9], const double t[3], double x[3]) {
-  const double c00 = W[4] * W[8] - W[5] * W[7];
-  const double c01 = W[5] * W[6] - W[3] * W[8];
-  const double c02 = W[3] * W[7] - W[4] * W[6];
-  const double det = W[0] * c00 + W[1] * c01 + W[2] * c02;
-  const double id = 1.0 / det;
-  const double c10 = W[2] * W[7] - W[1] * W[8];
-  const double c11 = W[0] * W[8] - W[2] * W[6];
-  const double c12 = W[1] * W[6] - W[0] * W[7];
-  const double c20 = W[1] * W[5] - W[2] * W[4];
-  const double c21 = W[2] * W[3] - W[0] * W[5];
-  const double c22 = W[0] * W[4] - W[1] * W[3];
-  x[0] = (c00 * t[0] + c10 * t[1] + c20 * t[2]) * id;
-  x[1] = (c01 * t[0] + c11 * t[1] + c21 * t[2]) * id;
-  x[2] = (c02 * t[0] + c12 * t[1] + c22 * t[2]) * id;
+// W x = t by LU with partial pivoting (TooN::LU, sim3_rv.h:305-307; Eigen lu().solve in g2o).  Where
+// the as-written B makes W nearly singular the pivoting order decides the rounding, so it is the
+// reference's, not an adjugate.  (Row swaps by selects: no dynamically indexed registers.)
+S3_HD void solve33(const double Win[9], const double tin[3], double x[3]) {
+  S3_STRICT_FP
+  double M[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[i][j] = Win[3 * i + j];
+    M[i][3] = tin[i];
+  }
+  auto swap_rows = [&](int a, int b, bool sw) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double u = M[a][j], v = M[b][j];
+      M[a][j] = sw ? v : u;
+      M[b][j] = sw ? u : v;
+    }
+  };
+  auto eliminate = [&](int c) {
+#pragma unroll
+    for (int r = c + 1; r < 3; ++r) {
+      const double f = M[r][c] / M[c][c];
+#pragma unroll
+      for (int j = c; j < 4; ++j) M[r][j] -= f * M[c][j];
+    }
+  };
+  {  // column 0: pivot = first row of maximal |.|, swapped with row 0
+    const bool p1 = fabs(M[1][0]) > fabs(M[0][0]);
+    const double best = p1 ? fabs(M[1][0]) : fabs(M[0][0]);
+    const bool p2 = fabs(M[2][0]) > best;
+    swap_rows(0, 1, p1 && !p2);
+    swap_rows(0, 2, p2);
+    eliminate(0);
+  }
+  swap_rows(1, 2, fabs(M[2][1]) > fabs(M[1][1]));
+  eliminate(1);
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    double acc = M[i][3];
+#pragma unroll
+    for (int j = i + 1; j < 3; ++j) acc -= M[i][j] * x[j];
+    x[i] = acc / M[i][i];
+  }
 }
 
 // Sim3::log()                                              (sim3_rv.h:242-320)
 S3_HD void log(const Sim3& S, const Opts& o, double xi[7]) {
+  S3_STRICT_FP
   const double s = S.s, sigma = ::log(s);
   double R[9];
   R_from_quat(S.q, R);
@@ -227,8 +288,11 @@ S3_HD void log(const Sim3& S, const Opts& o, double xi[7]) {
   const double om[3] = {k * dR[0], k * dR[1], k * dR[2]};
   double A, B, C;
   w_coeffs(sigma, s, theta, small, o.eps, o.fix_small_b, A, B, C);
-  double W[9], up[3];
-  w_matrix(om, A, B, C, W);
+  double Om[9], Om2[9], W[9], up[3];
+  skew_and_square(om, Om, Om2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = A * Om[i] + B * Om2[i];
+  W[0] += C; W[4] += C; W[8] += C;
   solve33(W, S.t, up);
   xi[0] = om[0]; xi[1] = om[1]; xi[2] = om[2];
   xi[3] = up[0]; xi[4] = up[1]; xi[5] = up[2];
@@ -237,7 +301,8 @@ S3_HD void log(const Sim3& S, const Opts& o, double xi[7]) {
 
 // EdgeSim3::computeError: e = log(C * S0 * S1^-1)  (edges set up at kitti_surf.cpp:633-638, :663-668)
 S3_HD void edge_error(const Sim3& C, const Sim3& S0, const Sim3& S1, const Opts& o, double e[7]) {
-  const Sim3 E = mul(mul(C, S0), inverse(S1));
+  const Sim3 S1i = inverse(S1);
+  const Sim3 E = mul(mul(C, S0), S1i);
   log(E, o, e);
 }
 

@@ -37,6 +37,7 @@ class Options(C.Structure):
         ("device", C.c_int32),
         ("verbose", C.c_int32),
         ("time_kernels", C.c_int32),
+        ("linear_solver", C.c_int32),
     ]
 
 
@@ -99,12 +100,16 @@ SYMBOLS = {
     "sim3opt_edge_errors": (C.c_int, [_vp, _dp]),
     "sim3opt_linearize": (C.c_int, [_vp]),
     "sim3opt_system_dims": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64)]),
+    "sim3opt_system_pattern": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64), _ip, _ip]),
     "sim3opt_get_system": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
     "sim3opt_preconditioner_in_use": (C.c_int, [_vp]),
     "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
+    "sim3opt_linear_solver_in_use": (C.c_int, [_vp]),
+    "sim3opt_direct_plan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), _ip, _ip, _ip, _ip, _ip, _ip,
+                                      _ip, _ip, _ip, _ip]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
@@ -396,6 +401,37 @@ class Graph:
         if rc < 0:
             self._chk(rc)
         return rc
+
+    def system_pattern(self):
+        """(rowptr, colidx) of the block-CSR system; host only."""
+        nb, nnzb = C.c_int32(), C.c_int64()
+        self._chk(self._L.sim3opt_system_pattern(self._g, C.byref(nb), C.byref(nnzb), None, None))
+        rowptr = np.zeros(nb.value + 1, dtype=np.int32)
+        colidx = np.zeros(max(nnzb.value, 1), dtype=np.int32)
+        self._chk(self._L.sim3opt_system_pattern(self._g, None, None, _p(rowptr, _ip), _p(colidx, _ip)))
+        return rowptr, colidx[:nnzb.value]
+
+    def linear_solver_in_use(self):
+        rc = self._L.sim3opt_linear_solver_in_use(self._g)
+        if rc < 0:
+            self._chk(rc)
+        return rc
+
+    def direct_plan(self, max_pairs=0):
+        """Plan of the exact sparse block Cholesky as a dict of numpy arrays; host only."""
+        dims = np.zeros(8, dtype=np.int64)
+        dp = dims.ctypes.data_as(C.POINTER(C.c_int64))
+        null = [None] * 10
+        self._chk(self._L.sim3opt_direct_plan(self._g, int(max_pairs), dp, *null))
+        nb, nL, npairs, height, ngroups, nlev, nsrc = (int(x) for x in dims[:7])
+        arr = dict(perm=nb, colptr=nb + 1, lrow=nL, srcptr=nL + 1, src=nsrc, pairptr=nL + 1,
+                   pa=npairs, pb=npairs, gptr=ngroups + 1, lcolp=nlev + 1)
+        out = {k: np.zeros(max(n, 1), dtype=np.int32) for k, n in arr.items()}
+        self._chk(self._L.sim3opt_direct_plan(self._g, int(max_pairs), dp,
+                                              *[_p(out[k], _ip) for k in arr]))
+        out = {k: out[k][:n] for k, n in arr.items()}
+        out.update(nb=nb, nL=nL, npairs=npairs, height=height, ngroups=ngroups, nlevels=nlev)
+        return out
 
     def amg_hierarchy(self):
         """(rows per level, blocks per level, level-1 row of every level-0 block row); host only."""

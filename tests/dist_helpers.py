@@ -20,3 +20,24 @@ def allgatherv(arr, offs, rank):
 def init(rank, world, port):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
                             world_size=world)
+
+
+_RENDEZVOUS_MARKERS = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset",
+                       "connect() timed out", "Socket Timeout", "failed to connect", "The server socket has failed")
+
+
+def is_rendezvous_error(exc):
+    """True only for a lost race on the TCP rendezvous port (a worker fault must NOT be retried)."""
+    msg = str(exc)
+    return any(m in msg for m in _RENDEZVOUS_MARKERS)
+
+
+def spawn_with_port_retry(spawn_once):
+    """Runs spawn_once() (an mp.spawn call on a fresh port); retries ONCE, and only when the failure
+    is the rendezvous itself -- any other worker exception propagates from the first attempt."""
+    try:
+        return spawn_once()
+    except Exception as e:  # noqa: BLE001 -- filtered just below
+        if not is_rendezvous_error(e):
+            raise
+    return spawn_once()

@@ -17,6 +17,8 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
+import dist_helpers as H
+
 
 def _free_port():
     s = socket.socket()
@@ -27,14 +29,9 @@ def _free_port():
 
 
 def _spawn(fn, world, out):
-    """mp.spawn with one retry on a fresh port (a rendezvous on a just-released port can lose a race)."""
-    for attempt in (0, 1):
-        try:
-            mp.spawn(fn, args=(world, _free_port(), out), nprocs=world, join=True)
-            return
-        except Exception:
-            if attempt == 1:
-                raise
+    """mp.spawn; one retry on a fresh port only when the TCP rendezvous itself lost a race."""
+    H.spawn_with_port_retry(
+        lambda: mp.spawn(fn, args=(world, _free_port(), out), nprocs=world, join=True))
 
 
 def _block_system(seed=0):

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
+import dist_helpers as H
+
 pytestmark = pytest.mark.gpu
 
 
@@ -64,16 +66,12 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
     products and restricted residuals, replicated coarse levels)."""
     from sim3opt_amd import lib as L, synth
     out = str(tmp_path / "r")
-    for attempt in (0, 1):  # one retry on a fresh port (a rendezvous on a just-released port can lose a race)
-        try:
-            mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True)
-            break
-        except Exception:
-            if attempt == 1:
-                raise
+    # (one retry on a fresh port, only if the TCP rendezvous itself lost a race for the port)
+    H.spawn_with_port_retry(
+        lambda: mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True))
     res = [np.load(out + f".{r}.npz") for r in range(world)]
     g = _graph(prec)
-    if prec == 2:  # the single-GPU default cycle is the additive one; compare like with like
+    if prec == 2:  # pin the cycle shape on both sides (env knobs reach the workers too)
         monkeypatch.setenv("SIM3OPT_AMG_ADDITIVE", "0")
         monkeypatch.setenv("SIM3OPT_AMG_CYCLE", "13")
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)

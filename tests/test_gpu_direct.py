@@ -1,0 +1,184 @@
+"""GPU tests (-m gpu) of the exact sparse block Cholesky (LinearSolverEigen's role,
+kitti_surf.cpp:553-554) and of KITTI-00 in the reference's OWN configuration: delta = 1e-9 numeric
+Jacobians, the small-angle B coefficient as written (sim3_rv.h:166, :290), optimize(100)
+(kitti_surf.cpp:674-675), first loop only (:1317) and all 118 loops.
+
+What "parity" can mean there: the configuration amplifies last-bit differences
+of libm by up to 1e3 per LM iteration, so
+  * LOCK-STEP (the rigorous check): every one of the first 20 iterations restarted from the
+    oracle's state and lambda -- identical trial counts, lambda and chi2 as close as the independent
+    numpy / scipy LM of tests/golden/make_lm_golden.py gets (tests/test_oracle.py);
+  * FREE RUN: identical accept / reject decisions for the first 9 iterations, the same number of
+    iterations as the oracle on the one-loop graph, final chi2 within 1e-3, trajectory RMSE against
+    the oracle below 1e-3 m (measured 1.6e-4; the oracle itself moves by 1.5e-4 under a 1e-15 input
+    perturbation); on the 118-loop graph the three implementations at hand end in three different
+    local minima (chi2 17.8 / 20.70 / 20.75), which the test records instead of hiding."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sim3opt_amd import lib as L, sim3np as S3, synth
+import kitti_graph as K
+
+pytestmark = pytest.mark.gpu
+LMGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kitti_lm_golden.json")))
+
+
+def mk(g, **opts):
+    G = L.Graph(**opts)
+    G.add_vertices(g["states"], g["fixed"])
+    G.add_edges(g["v0"], g["v1"], g["meas"])
+    G.initialize()
+    return G
+
+
+def oracle_of(g):
+    return O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
+
+
+# ------------------------------------------------------------------ the factorisation itself
+CASES = {
+    "kitti_one_loop": (lambda: K.build_direct_graph(True), {}),
+    "kitti_all_loops": (lambda: K.build_direct_graph(False), {}),
+    "chain_200": (lambda: synth.chain_loop(200, 230), {}),
+    "tiny_5": (lambda: synth.chain_loop(5, 6, min_gap=2), {}),
+    # heavy fill: only on request
+    "manhattan_300": (lambda: synth.manhattan(300, 1500, dims=(8, 8, 3)), dict(linear_solver=1)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_direct_solve_matches_dense(name):
+    make, opts = CASES[name]
+    G = mk(make(), fix_small_angle_b=1, **opts)
+    assert G.linear_solver_in_use() == 1
+    G.linearize()
+    H, b = G.dense_system()
+    n = H.shape[0]
+    for lam in (1e-2, 1.0, 1e3):
+        x, it, _ = G.solve(lam)
+        A = H + lam * np.eye(n)
+        xr = np.linalg.solve(A, b)
+        assert it == 0  # no iterations: a factorisation
+        assert np.abs(A @ x - b).max() < 1e-12 * max(np.abs(b).max(), 1e-300) * n
+        assert np.abs(x - xr).max() < 1e-8 * np.abs(xr).max()
+    x2, _, _ = G.solve(1e3)
+    assert np.array_equal(x, x2)  # fixed summation order: bit-reproducible
+
+
+def test_direct_reports_indefinite_system():
+    """Non-positive pivot = g2o's `solve` returning false: the C-ABI reports it, LM would reject."""
+    G = mk(K.build_direct_graph(True))
+    assert G.linear_solver_in_use() == 1
+    G.linearize()
+    with pytest.raises(L.Sim3OptError):
+        G.solve(-1e15)
+    x, _, _ = G.solve(1.0)  # the next solve is unaffected
+    assert np.isfinite(x).all()
+
+
+def test_linear_solver_option():
+    g = synth.chain_loop(200, 230)
+    assert mk(g, linear_solver=0).linear_solver_in_use() == 0
+    assert mk(g, linear_solver=-1).linear_solver_in_use() == 1
+    # heavy fill: automatic = PCG, forced = exact
+    g = synth.manhattan(1000, 10000, dims=(10, 10, 5))
+    assert mk(g).linear_solver_in_use() == 0
+    # exact and iterative steps agree on a well-posed graph
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(150, 900, dims=(5, 5, 3), per_cell=4)
+    Gd = mk(g, linear_solver=1, fix_small_angle_b=1, fd_delta=1e-6)
+    Gi = mk(g, linear_solver=0, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-13)
+    assert Gd.optimize(6) == Gi.optimize(6) == 6
+    assert abs(Gd.stats()[-1].chi2_after - Gi.stats()[-1].chi2_after) < 1e-8 * Gi.stats()[-1].chi2_after
+    assert synth.rmse(Gd.get_vertices(), Gi.get_vertices()) < 1e-6
+
+
+# ------------------------------------------------------------------ KITTI-00, reference configuration
+@pytest.mark.parametrize("name,one", [("one_loop", True), ("all_loops", False)])
+def test_kitti_lockstep_with_oracle(name, one):
+    """Each of the first 20 LM iterations from the oracle's state and lambda: same trial counts as the
+    oracle (and as the independent LM of the fixture), chi2 to 1e-6 in most iterations and to 2e-3
+    in the sensitive ones.  There the device's H and b equal the oracle's to 1e-13 (the Sim(3)
+    arithmetic is restated operation by operation, scripts/gpu_bitparity.py), and the remaining
+    difference is the rounding of two exact factorisations of a matrix with cond ~ 4e11 (different
+    elimination orders): the independent SuperLU solve of the fixture differs from the oracle's
+    LDL^T by as much."""
+    gold = LMGOLD[name]["lockstep"]
+    g = K.build_direct_graph(one)
+    OG = oracle_of(g)
+    G = mk(g)
+    assert G.linear_solver_in_use() == 1
+    lam = None
+    tight = 0
+    worst = 0.0
+    for k, rec in enumerate(gold):
+        G.set_vertices(OG.states)
+        G.set_options(user_lambda_init=lam if lam is not None else 0.0)
+        assert G.optimize(1) == 1
+        s = G.stats()[0]
+        it, tr = OG.optimize(1, O.default_options(user_lambda_init=lam if lam is not None else 0.0))
+        t = tr[0]
+        assert t.trials == rec["oracle_trials"]  # the oracle is where the fixture left it
+        assert s.trials == t.trials, (k, s.trials, t.trials)
+        rel = abs(s.chi2_after - t.chi2_after) / t.chi2_after
+        worst = max(worst, rel)
+        assert rel < 2e-3, (k, rel)
+        assert abs(s.lambda_ - t.lambda_) <= max(1e-6, 2 * rel) * t.lambda_, k
+        tight += rel < 1e-6
+        lam = t.lambda_
+    assert tight >= 15, (tight, worst)
+
+
+def test_kitti_one_loop_reference_run():
+    """optimize(100) as kitti_surf.cpp:675 calls it, default options, `bUseOneContraint` graph."""
+    g = K.build_direct_graph(True)
+    OG = oracle_of(g)
+    t0 = time.perf_counter()
+    it, tr = OG.optimize(100)
+    t_cpu = time.perf_counter() - t0
+    G = mk(g)
+    G.optimize(2)  # warm-up (first launches, clocks)
+    G.set_vertices(g["states"])
+    t0 = time.perf_counter()
+    n = G.optimize(100)
+    t_gpu = time.perf_counter() - t0
+    st = G.stats()
+    assert n == it == 100
+    assert [s.trials for s in st[:9]] == [t.trials for t in tr[:9]] == [1, 1, 5, 1, 2, 7, 1, 1, 3]
+    for k in range(9):
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 5e-3 * tr[k].chi2_after, k
+    assert abs(st[-1].chi2_after - tr[-1].chi2_after) < 1e-3 * tr[-1].chi2_after
+    assert abs(st[-1].chi2_after - 1.2091) < 2e-3
+    rm = synth.rmse(G.get_vertices(), OG.states)
+    assert rm < 1e-3, rm  # measured 1.6e-4; the oracle's own sensitivity is 1.5e-4
+    # the whole run is faster than the single-thread CPU restatement (the reference's execution model)
+    assert t_gpu < t_cpu, (t_gpu, t_cpu)
+    # a second run from the same start is bit-identical
+    G.set_vertices(g["states"])
+    assert G.optimize(100) == 100
+    assert [s.chi2_after for s in G.stats()] == [s.chi2_after for s in st]
+
+
+def test_kitti_all_loops_reference_run():
+    """All 118 loop constraints (`bUseOneContraint = false`).  The head of the run follows the oracle
+    (1e-3 for five iterations, identical decisions for seven); after that this configuration sends
+    every implementation to its own local minimum -- oracle 20.75 (Terminate at 41), independent
+    numpy LM 20.70 (Terminate at 40), survey probe 18.56, this path 17.8 -- so only the quality of
+    the end point is asserted: chi2 not above the oracle's, Terminate reached before 100."""
+    g = K.build_direct_graph(False)
+    OG = oracle_of(g)
+    it, tr = OG.optimize(100)
+    G = mk(g)
+    n = G.optimize(100)
+    st = G.stats()
+    for k in range(5):
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 1e-3 * tr[k].chi2_after, k
+    assert [s.trials for s in st[:7]] == [t.trials for t in tr[:7]]
+    assert n < 100 and it < 100
+    assert st[-1].chi2_after < 1.02 * tr[-1].chi2_after
+    assert np.isfinite(G.get_vertices()).all()

@@ -160,7 +160,7 @@ def test_ids_fixed_vertices_and_parallel_edges():
 # ------------------------------------------------------------------ linear solve
 def test_pcg_matches_dense_and_oracle_ldlt():
     g = small(3, V=120, E=900)
-    G, OG = mk(g, fd_delta=1e-6, pcg_rel_tol=1e-12), oracle_of(g)
+    G, OG = mk(g, fd_delta=1e-6, pcg_rel_tol=1e-12, linear_solver=0), oracle_of(g)
     G.linearize()
     H, b = G.dense_system()
     lam = 1e-5 * np.abs(np.diag(H)).max()
@@ -183,7 +183,7 @@ def test_chain_segment_preconditioner_on_kitti():
     sol = {}
     for pre in (0, 1, -1):
         G = mk(g, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, pcg_max_iters=40000,
-               preconditioner=pre)
+               preconditioner=pre, linear_solver=0)  # (automatic solver choice here: the exact one)
         G.linearize()
         H, b = G.dense_system()
         lam = 1e-5 * np.abs(np.diag(H)).max()
@@ -201,7 +201,7 @@ def test_chain_segment_preconditioner_on_kitti():
     its = {}
     for pre in (0, -1):
         G = mk(g, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-10, preconditioner=pre,
-               pcg_max_iters=40000)
+               pcg_max_iters=40000, linear_solver=0)
         G.linearize()
         its[pre] = G.solve(1.0)[1]
     assert its[-1] < its[0]  # (over a whole LM run: 15 404 against 781 311 iterations)
@@ -236,7 +236,7 @@ def test_multigrid_preconditioner_solution_and_iterations(monkeypatch):
     # automatic rule: this graph coarsens well -> multigrid; <= 256 rows -> no hierarchy; config 2
     # (random long-range loops: an expander, level-1 blocks 0.47 of level 0) -> block-Jacobi
     assert mk(g, fix_small_angle_b=1).preconditioner_in_use() == 2
-    assert mk(small(3, V=120, E=900), fix_small_angle_b=1).preconditioner_in_use() == 0
+    assert mk(small(3, V=120, E=900), fix_small_angle_b=1, linear_solver=0).preconditioner_in_use() == 0
     assert mk(synth.chain_loop(3000, 6000), fix_small_angle_b=1).preconditioner_in_use() == 0
     assert mk(g).preconditioner_in_use() == 0  # reference arithmetic as written: never automatic
     G.linearize()
@@ -303,7 +303,7 @@ def test_multigrid_lm_matches_oracle():
 
 def test_pcg_reports_breakdown_on_indefinite_system():
     g = small(3)
-    G = mk(g)
+    G = mk(g, linear_solver=0)
     G.linearize()
     with pytest.raises(L.Sim3OptError):
         G.solve(-1e12)

@@ -224,6 +224,67 @@ def test_kitti_lm_head_matches_golden_and_survey():
     assert all(chi[i + 1] <= chi[i] for i in range(3))
 
 
+# ------------------------------------------------------------------ the LM trace, pinned independently
+LMGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kitti_lm_golden.json")))
+
+
+@pytest.mark.parametrize("name,one", [("one_loop", True), ("all_loops", False)])
+def test_kitti_lm_lockstep_matches_independent_lm(name, one):
+    """Every LM iteration of the oracle on KITTI-00, reference configuration (delta = 1e-9, B as
+    written), against ONE iteration of an independent numpy / scipy restatement started from the
+    oracle's own state and lambda (tests/golden/make_lm_golden.py: numpy Sim(3) arithmetic, its own
+    central differences, scipy COO assembly, SuperLU solve, its own LM policy).  An iteration ends
+    with nu = 2, so (estimates, lambda) is the whole LM state and `user_lambda_init` restarts it.
+    Trial counts are identical in all 20 iterations; chi2 (and with it lambda) to 1e-6 in 17 / 18 of the 20
+    iterations and to 5e-4 in the sensitive ones (the configuration amplifies last-bit differences
+    of libm by up to 1e3 per iteration, see the free-run test)."""
+    gold = LMGOLD[name]["lockstep"]
+    g = K.build_direct_graph(one)
+    G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
+    lam = None
+    tight = 0
+    for k, rec in enumerate(gold):
+        o = O.default_options(user_lambda_init=lam if lam is not None else 0.0)
+        it, tr = G.optimize(1, o)
+        assert it == 1
+        t = tr[0]
+        # the fixture was generated from this very oracle: it must not have drifted
+        assert abs(t.chi2_after - rec["oracle_chi2"]) <= 1e-9 * rec["oracle_chi2"], k
+        assert t.trials == rec["oracle_trials"]
+        # ... and the independent implementation took the same decisions from the same state
+        assert t.trials == rec["trials"], (k, t.trials, rec["trials"])
+        rel = abs(t.chi2_after - rec["chi2"]) / rec["chi2"]
+        assert rel < 5e-4, (k, rel)
+        # (lambda's factor is a function of the gain ratio, i.e. of the new chi2)
+        assert abs(t.lambda_ - rec["lam"]) <= max(1e-6, 2 * rel) * rec["lam"], k
+        tight += rel < 1e-6
+        lam = t.lambda_
+    assert tight >= 17
+
+
+@pytest.mark.parametrize("name,one,same_trials", [("one_loop", True, 9), ("all_loops", False, 13)])
+def test_kitti_lm_free_run_follows_independent_lm(name, one, same_trials):
+    """Free runs: the oracle and the independent LM take identical accept / reject decisions for the
+    first 9 (one loop) / 13 (118 loops) iterations and stay within 1e-2 in chi2 for 20; both stop the
+    118-loop run through g2o's Terminate rule at iteration 40 / 41 (chi2 20.70 / 20.75; the survey's
+    probe, BASELINE.md section 3, reports 18.56 after 99: a third trajectory of the same chaotic map,
+    and 4.36 after iteration 2 where these two give 4.324 and 4.332)."""
+    gold = LMGOLD[name]["free"]
+    g = K.build_direct_graph(one)
+    G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
+    it, tr = G.optimize(len(gold["chi2"]))
+    assert it == len(gold["chi2"])
+    assert [t.trials for t in tr[:same_trials]] == gold["trials"][:same_trials]
+    for k in range(it):
+        assert abs(tr[k].chi2_after - gold["chi2"][k]) < 1e-2 * gold["chi2"][k], k
+    for k in range(same_trials):
+        assert abs(tr[k].lambda_ - gold["lam"][k]) < 1e-2 * gold["lam"][k], k
+    # final poses of the two 20-iteration runs: the CPU-vs-CPU spread of this configuration
+    t_wi = S3.inv(G.states)[:, 4:7]
+    rm = np.sqrt(((t_wi - np.array(gold["t_wi"])) ** 2).sum(1).mean())
+    assert rm < (2e-3 if one else 0.5), rm
+
+
 # ------------------------------------------------------------------ normal equations, solver, LM
 def small_graph(seed=0, info=False, kernel=0):
     synth.DRIFT_TARGET = 0.05
