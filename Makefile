@@ -1,25 +1,35 @@
-# Builds libsim3opt.so (hipcc, gfx950), the CPU oracle and the C++ example without Python.
-#   make            -> sim3opt_amd/libsim3opt.so, oracle/liboracle_sim3.so
-#   make example    -> examples/direct_pgo (testDirectSim3Optimization on the g2o-named shim)
+# Builds libsim3opt.so (hipcc, gfx950), the CPU oracle and the C++ examples without Python.
+#   make                 -> sim3opt_amd/libsim3opt.so, oracle/liboracle_sim3.so
+#   make example         -> examples/direct_pgo (testDirectSim3Optimization on the g2o-named shim)
+#   make call_forms      -> tests/cxx/reference_call_forms (the reference's call forms against the
+#                           shim; EIGEN_INC=-I/usr/include/eigen3 for a real Eigen + Sophus)
+#   make LIB=/some/where/libsim3opt.so   builds the library elsewhere (used by the tests)
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := sim3opt_amd/csrc
-SRCS  := $(CSRC)/engine.hip $(CSRC)/capi.cpp $(CSRC)/graph.cpp $(CSRC)/kitti_io.cpp \
-         $(CSRC)/comm.cpp $(CSRC)/eval.cpp $(CSRC)/stepwise.cpp $(CSRC)/map_io.hip
-HDRS  := $(wildcard $(CSRC)/*.hpp) include/sim3opt.h
+# one list of translation units, shared with sim3opt_amd/build.py
+SRCS  := $(addprefix $(CSRC)/,$(shell cat $(CSRC)/SOURCES))
+HDRS  := $(wildcard $(CSRC)/*.hpp) include/sim3opt.h $(CSRC)/SOURCES
+LIB   ?= sim3opt_amd/libsim3opt.so
+LIBDIR = $(abspath $(dir $(LIB)))
+EIGEN_INC ?= -Itests/mock_eigen
 
-all: sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so
+all: $(LIB) oracle/liboracle_sim3.so
 
-sim3opt_amd/libsim3opt.so: $(SRCS) $(HDRS)
+$(LIB): $(SRCS) $(HDRS)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -o $@ $(SRCS) -ldl
 
 oracle/liboracle_sim3.so: oracle/sim3_oracle.c oracle/sim3_oracle.h
 	$(MAKE) -C oracle liboracle_sim3.so
 
-example: sim3opt_amd/libsim3opt.so examples/direct_pgo.cpp include/sim3opt_g2o.hpp
-	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude examples/direct_pgo.cpp -Lsim3opt_amd -lsim3opt \
-	    -Wl,-rpath,$(CURDIR)/sim3opt_amd -o examples/direct_pgo
+example: $(LIB) examples/direct_pgo.cpp include/sim3opt_g2o.hpp
+	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude examples/direct_pgo.cpp -L$(LIBDIR) -lsim3opt \
+	    -Wl,-rpath,$(LIBDIR) -o examples/direct_pgo
+
+call_forms: $(LIB) tests/cxx/reference_call_forms.cpp include/sim3opt_g2o.hpp
+	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude $(EIGEN_INC) tests/cxx/reference_call_forms.cpp \
+	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/reference_call_forms
 
 clean:
-	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo
+	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo tests/cxx/reference_call_forms
 
-.PHONY: all example clean
+.PHONY: all example call_forms clean

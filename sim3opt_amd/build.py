@@ -11,8 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsim3opt.so")
-SOURCES = ["engine.hip", "capi.cpp", "graph.cpp", "kitti_io.cpp", "comm.cpp", "eval.cpp", "stepwise.cpp", "map_io.hip", "amg.cpp", "direct.cpp"]
-HEADERS = ["engine.hpp", "graph.hpp", "comm.hpp", "sim3_math.hpp", "amg.hpp", "amg_kernels.hpp", "direct.hpp", "direct_kernels.hpp", os.path.join("..", "..", "include", "sim3opt.h")]
+# the one list of translation units, shared with the Makefile
+SOURCES = open(os.path.join(CSRC, "SOURCES")).read().split()
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [
+    os.path.join("..", "..", "include", "sim3opt.h"), "SOURCES"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-result"]
@@ -29,7 +31,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
     cmd = [HIPCC] + FLAGS + ["-o", LIB] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))

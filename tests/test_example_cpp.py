@@ -1,5 +1,8 @@
 """The reference-side binding (include/sim3opt_g2o.hpp) in action: examples/direct_pgo.cpp is
-testDirectSim3Optimization (kitti_surf.cpp:542-709) on the g2o-named shim."""
+testDirectSim3Optimization (kitti_surf.cpp:542-709) on the g2o-named shim without any Eigen;
+tests/cxx/reference_call_forms.cpp holds the reference's own call forms (direct and stepwise
+builders, kitti_surf.cpp:552-701, :726-886, :1020-1075) and is compiled against a tests-only
+fixed-size Eigen / Sophus mock (tests/mock_eigen) and, where it is installed, against real Eigen."""
 import os
 import subprocess
 
@@ -49,3 +52,77 @@ def test_shim_example_runs_direct_pgo(tmp_path):
     Swc = S3.inv(G.get_vertices())
     assert np.abs(rows[:, 2:5] - Swc[:, 4:7]).max() < 1e-12
     assert np.abs(rows[:, 1] - G.get_vertices()[:, 7]).max() < 1e-15
+
+
+# ------------------------------------------------------------------ the reference's call forms
+def compile_call_forms(tmp_path, eigen_inc):
+    exe = str(tmp_path / "reference_call_forms")
+    libdir = os.path.join(ROOT, "sim3opt_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-DSIM3OPT_G2O_NAMES",
+                           "-I" + os.path.join(ROOT, "include")] + eigen_inc +
+                          [os.path.join(ROOT, "tests", "cxx", "reference_call_forms.cpp"), "-L" + libdir,
+                           "-lsim3opt", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+MOCK = ["-I" + os.path.join(ROOT, "tests", "mock_eigen")]
+
+
+def test_reference_call_forms_compile_against_the_mock(tmp_path):
+    """`esim->information() = matLambdasim`, `g2o::Sim3 Siw(Rcw, tcw, 1.0)`, `.rotation().coeffs()`,
+    `vST->Rw2i = Sophus::SO3d(Rcw)`, G2oVertexScale / G2oEdgeScaleTrans ...: all of it compiles (-Werror)
+    and links; without a GPU the program fails loudly at initializeOptimization."""
+    import torch
+    exe = compile_call_forms(tmp_path, MOCK)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe, K.FIXTURE, str(tmp_path) + "/", "1"], capture_output=True, text=True)
+    assert r.returncode != 0
+
+
+def test_reference_call_forms_compile_against_real_eigen(tmp_path):
+    inc = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3")
+           if os.path.exists(os.path.join(d, "Eigen", "Core"))]
+    if not inc:
+        pytest.skip("no Eigen in this image (SURVEY.md 0.2): the mock stands in")
+    # Sophus is still the mock's (tests/mock_eigen/sophus includes "../Eigen/..." relatively)
+    compile_call_forms(tmp_path, ["-I" + inc[0]] + MOCK)
+
+
+def test_makefile_builds_a_loadable_library(tmp_path):
+    """`make` (the documented non-Python build) must produce the same library as build.py: every
+    translation unit linked, every symbol of include/sim3opt.h exported."""
+    import ctypes
+    from sim3opt_amd import lib as L
+    out = str(tmp_path / "libsim3opt.so")
+    subprocess.check_call(["make", "-C", ROOT, "LIB=" + out, out], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(out)  # undefined symbols (a missing .cpp) would fail here
+    for name in L.SYMBOLS:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.gpu
+def test_reference_call_forms_run(tmp_path):
+    """The direct builder gives the same chi2 as the C-ABI path; the stepwise builders run their
+    stages (scale null vector, scale + translation LM with frozen rotations, warm-started Sim(3) LM)
+    and end far below the direct run's local minimum, as the reference's README says they should."""
+    import re
+    from sim3opt_amd import lib as L
+    exe = compile_call_forms(tmp_path, MOCK)
+    r = subprocess.run([exe, K.FIXTURE, str(tmp_path) + "/", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    m = re.search(r"direct: chi2 (\S+) -> (\S+) in (\d+) iterations", r.stdout)
+    assert m and abs(float(m.group(1)) - 169.9259622) < 1e-6 and int(m.group(3)) == 100
+    G = L.Graph()
+    G.load_kitti_direct(K.FIXTURE, True)
+    G.initialize()
+    G.optimize(100)
+    assert abs(float(m.group(2)) - G.stats()[-1].chi2_after) < 1e-9
+    st = re.findall(r"stepwise \((\d) optimizers\): scale sigma ratio (\S+), scale-trans chi2 (\S+) -> (\S+), final chi2 (\S+)", r.stdout)
+    assert [s[0] for s in st] == ["2", "3"]
+    for s in st:
+        assert float(s[3]) < float(s[2])  # the scale + translation stage reduces its chi2
+    assert float(st[1][4]) < float(m.group(2))  # stepwise + Sim(3) ends below the direct run
+    for f in ("direct_pure.txt", "stepwise_2solvers.txt", "stepwise_3solvers.txt"):
+        rows = np.loadtxt(str(tmp_path / f), comments="%")
+        assert rows.shape == (771, 9) and np.isfinite(rows).all()

@@ -8,11 +8,12 @@ of libm by up to 1e3 per LM iteration, so
   * LOCK-STEP (the rigorous check): every one of the first 20 iterations restarted from the
     oracle's state and lambda -- identical trial counts, lambda and chi2 as close as the independent
     numpy / scipy LM of tests/golden/make_lm_golden.py gets (tests/test_oracle.py);
-  * FREE RUN: identical accept / reject decisions for the first 9 iterations, the same number of
-    iterations as the oracle on the one-loop graph, final chi2 within 1e-3, trajectory RMSE against
-    the oracle below 1e-3 m (measured 1.6e-4; the oracle itself moves by 1.5e-4 under a 1e-15 input
-    perturbation); on the 118-loop graph the three implementations at hand end in three different
-    local minima (chi2 17.8 / 20.70 / 20.75), which the test records instead of hiding."""
+  * FREE RUN: the device evaluates residuals and numeric Jacobians in the oracle's operation order
+    without FMA contraction (sim3_math.hpp), so H and b agree to 1e-13 and the free runs stay
+    together: one loop -- 100 iterations on both sides, identical accept / reject decisions for 15,
+    final chi2 to 1.4e-6, trajectory RMSE 5.9e-6 m (north_star: < 1e-4); 118 loops -- identical
+    decisions for 11 iterations, Terminate at 39 / 41, RMSE 7.7e-4 m (the oracle's own sensitivity
+    there is 1.5 m)."""
 import json
 import os
 import time
@@ -135,7 +136,11 @@ def test_kitti_lockstep_with_oracle(name, one):
 
 
 def test_kitti_one_loop_reference_run():
-    """optimize(100) as kitti_surf.cpp:675 calls it, default options, `bUseOneContraint` graph."""
+    """optimize(100) as kitti_surf.cpp:675 calls it, default options, `bUseOneContraint` graph
+    (BASELINE.json configs[0] the way case 3 runs it, kitti_surf.cpp:1317): the north_star bar --
+    trajectory RMSE against the reference solver below 1e-4 m (measured 5.9e-6), same number of
+    iterations, identical accept / reject decisions for the first 12 iterations (measured: 15), final
+    chi2 to 1e-4 (measured 1.4e-6), and faster than the single-thread CPU path."""
     g = K.build_direct_graph(True)
     OG = oracle_of(g)
     t0 = time.perf_counter()
@@ -149,15 +154,16 @@ def test_kitti_one_loop_reference_run():
     t_gpu = time.perf_counter() - t0
     st = G.stats()
     assert n == it == 100
-    assert [s.trials for s in st[:9]] == [t.trials for t in tr[:9]] == [1, 1, 5, 1, 2, 7, 1, 1, 3]
-    for k in range(9):
-        assert abs(st[k].chi2_after - tr[k].chi2_after) < 5e-3 * tr[k].chi2_after, k
-    assert abs(st[-1].chi2_after - tr[-1].chi2_after) < 1e-3 * tr[-1].chi2_after
-    assert abs(st[-1].chi2_after - 1.2091) < 2e-3
+    assert [s.trials for s in st[:12]] == [t.trials for t in tr[:12]]
+    assert [s.trials for s in st[:9]] == [1, 1, 5, 1, 2, 7, 1, 1, 3]
+    for k in range(12):
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 1e-3 * tr[k].chi2_after, k
+    assert abs(st[-1].chi2_after - tr[-1].chi2_after) < 1e-4 * tr[-1].chi2_after
+    assert abs(st[-1].chi2_after - 1.2091) < 1e-3
     rm = synth.rmse(G.get_vertices(), OG.states)
-    assert rm < 1e-3, rm  # measured 1.6e-4; the oracle's own sensitivity is 1.5e-4
+    assert rm < 1e-4, rm
     # the whole run is faster than the single-thread CPU restatement (the reference's execution model)
-    assert t_gpu < t_cpu, (t_gpu, t_cpu)
+    assert t_gpu < 0.5 * t_cpu, (t_gpu, t_cpu)
     # a second run from the same start is bit-identical
     G.set_vertices(g["states"])
     assert G.optimize(100) == 100
@@ -165,11 +171,11 @@ def test_kitti_one_loop_reference_run():
 
 
 def test_kitti_all_loops_reference_run():
-    """All 118 loop constraints (`bUseOneContraint = false`).  The head of the run follows the oracle
-    (1e-3 for five iterations, identical decisions for seven); after that this configuration sends
-    every implementation to its own local minimum -- oracle 20.75 (Terminate at 41), independent
-    numpy LM 20.70 (Terminate at 40), survey probe 18.56, this path 17.8 -- so only the quality of
-    the end point is asserted: chi2 not above the oracle's, Terminate reached before 100."""
+    """All 118 loop constraints (`bUseOneContraint = false`).  The run is more sensitive than the
+    one-loop one (the oracle itself moves by 1.5 m RMSE under a 1e-15 input perturbation, and the
+    independent numpy LM of the fixture ends at chi2 20.70 where the oracle ends at 20.75): measured
+    here 7.7e-4 m RMSE against the oracle, identical decisions for 11 iterations, Terminate at 39
+    against 41, final chi2 within 1.7e-3."""
     g = K.build_direct_graph(False)
     OG = oracle_of(g)
     it, tr = OG.optimize(100)
@@ -177,8 +183,11 @@ def test_kitti_all_loops_reference_run():
     n = G.optimize(100)
     st = G.stats()
     for k in range(5):
-        assert abs(st[k].chi2_after - tr[k].chi2_after) < 1e-3 * tr[k].chi2_after, k
-    assert [s.trials for s in st[:7]] == [t.trials for t in tr[:7]]
-    assert n < 100 and it < 100
-    assert st[-1].chi2_after < 1.02 * tr[-1].chi2_after
-    assert np.isfinite(G.get_vertices()).all()
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 1e-4 * tr[k].chi2_after, k
+    for k in range(10):
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 2e-2 * tr[k].chi2_after, k
+    assert [s.trials for s in st[:10]] == [t.trials for t in tr[:10]]
+    assert n < 100 and it < 100 and abs(n - it) <= 5  # g2o's Terminate rule fires on both sides
+    assert abs(st[-1].chi2_after - tr[-1].chi2_after) < 1e-2 * tr[-1].chi2_after
+    rm = synth.rmse(G.get_vertices(), OG.states)
+    assert rm < 1e-2, rm
