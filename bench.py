@@ -13,8 +13,9 @@ across the ranks (strong scaling), RCCL all-gather of the PCG direction + fused 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel (k_spmv: block-CSR SpMV of the PCG) against the 8 TB/s HBM peak,
                 duration measured live with HIP events on the library's stream in the timed region
-  cpu_baseline  the CPU oracle (port of the reference's g2o configuration) timed on rank 0 on a
-                bounded sample of the same workload
+  cpu_baseline  the CPU oracle (port of the reference's g2o configuration) timed on rank 0 on the
+                phases of the same workload a CPU can run at full size; plus the KITTI-00 table
+                (reference configuration) where both sides run the whole optimisation
 """
 import argparse
 import json
@@ -62,41 +63,93 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, threads=1, budget_s=10.0):
-    """Times the oracle on a bounded Manhattan sample.  threads=1 is the reference's execution
-    model (no OpenMP in its build, CMakeLists.txt:17-18); threads>1 parallelises the per-edge
-    loops only (the sparse LDL^T stays serial)."""
+def cpu_baseline(args, g, gpu_ms_linearize, gpu_value, threads=1):
+    """The CPU oracle (restatement of the reference's g2o configuration, single thread like the
+    reference: no OpenMP in its build, CMakeLists.txt:17-18) on the SAME graph the GPU just ran:
+    the phases a CPU can run at full size in bounded time -- numeric-Jacobian linearisation of every
+    edge (EdgeSim3::linearizeOplus) and one chi2 evaluation.  The exact sparse Cholesky of the
+    100k/1M Manhattan graph is out of reach (fill), so the CPU's linear solve is left out ENTIRELY:
+    `value` is an upper bound on the CPU's LM iterations/s and the quoted speed-up a lower bound.
+    What the solve costs on a graph small enough to factor is reported under `solve_sample`."""
     from oracle import oracle as O
-    from sim3opt_amd import synth
-    Vs = args.cpu_sample_vertices
-    Es = 10 * Vs
-    side = max(4, int(round((Vs / 10.0) ** 0.5)))
-    g = synth.manhattan(Vs, Es, dims=(side, side, 10), per_cell=4)
-    G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
     o = O.default_options(fix_small_angle_b=args.fix_small_angle_b, threads=threads)
+    G = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
     t0 = time.perf_counter()
-    iters = 0
-    trace = []
-    while iters < 2 or (time.perf_counter() - t0 < budget_s and iters < 50):
-        it, tr = G.optimize(1, o)
-        if it < 1:
-            break
-        iters += it
-        trace += tr
-    dt = time.perf_counter() - t0
-    lin = sum(t.t_linearize for t in trace)
-    sol = sum(t.t_solve for t in trace)
+    chi = G.chi2(o)
+    t_chi = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    G.jacobians(o)
+    t_lin = time.perf_counter() - t0
+    # solve phase: the largest sample the oracle's LDL^T factors in about ten seconds
+    from sim3opt_amd import lib as L, synth
+    Vs = args.cpu_sample_vertices
+    side = max(4, int(round((Vs / 10.0) ** 0.5)))
+    gs = synth.manhattan(Vs, 10 * Vs, dims=(side, side, 10), per_cell=4)
+    Gs = O.Graph(gs["states"], gs["fixed"], gs["v0"], gs["v1"], gs["meas"])
+    it, tr = Gs.optimize(2, o)
+    solves = sum(t.trials for t in tr)
+    t_solve = sum(t.t_solve for t in tr) / max(solves, 1)
+    lnz = int(O.lib().or_last_lnz())
+    # is the oracle's ordering a strawman?  fill of a nested-dissection order of the same sample
+    P = L.Graph()
+    P.add_vertices(gs["states"], gs["fixed"])
+    P.add_edges(gs["v0"], gs["v1"], gs["meas"])
+    nd = P.direct_plan(max_pairs=200_000_000)
+    P.close()
+    value = 1.0 / (t_lin + t_chi)
     return {
-        "value": Es * iters / dt, "unit": "edges*iters/s", "cores": threads, "kind": "port",
-        "sample": (f"Manhattan graph of the same generator, {Vs} vertices / {Es} edges, {iters} LM "
-                   f"iterations in {dt:.1f}s, {threads} thread(s); exact sparse LDL^T fill "
-                   f"{O.lib().or_last_lnz()} nonzeros; the 100k/1M graph itself is out of reach "
-                   f"of an exact CPU Cholesky in bounded time"),
-        "lm_iters_per_s_on_sample": iters / dt,
-        "lm_iters_per_s_extrapolated_to_workload": (Es * iters / dt) / args.edges,
-        "phase_split_s": {"linearize": lin, "solve": sol,
-                          "update": sum(t.t_update for t in trace)},
+        "value": value, "unit": "LM iter/s", "cores": threads, "kind": "port",
+        "sample": (f"configs[2] itself, {args.vertices} vertices / {args.edges} edges, full size: one "
+                   f"numeric-Jacobian linearisation of all edges ({t_lin:.2f} s) + one chi2 evaluation "
+                   f"({t_chi:.2f} s), {threads} thread; the CPU's sparse Cholesky is EXCLUDED (fill makes "
+                   f"it impractical at this size), so value is an upper bound on the CPU rate"),
+        "seconds": {"linearize": t_lin, "chi2": t_chi}, "chi2": chi,
+        "gpu_same_phase_ms": {"linearize_plus_chi2": gpu_ms_linearize},
+        "speedup_linearize_phase": (t_lin + t_chi) / (gpu_ms_linearize * 1e-3) if gpu_ms_linearize else None,
+        "speedup_lm_iters_lower_bound": gpu_value / value,
+        "solve_sample": {
+            "graph": f"Manhattan graph of the same generator, {Vs} vertices / {10 * Vs} edges",
+            "seconds_per_factor_and_solve": t_solve, "solves": solves,
+            "fill_nonzeros_min_degree": lnz,
+            "fill_nonzeros_nested_dissection": int(nd["nL"]) * 49,
+            "note": "the oracle's block-minimum-degree fill against a nested-dissection order of the "
+                    "same sample (sim3opt_direct_plan): the CPU factorisation is not handicapped by "
+                    "its ordering"},
     }
+
+
+def kitti_table(device):
+    """BASELINE.json configs[0] (and its all-loops variant) in the reference's OWN configuration
+    (delta = 1e-9, B as written, optimize(100), kitti_surf.cpp:674-675): both sides actually run."""
+    from oracle import oracle as O
+    from sim3opt_amd import lib as L, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kitti_graph as K
+    out = {}
+    for name, one in (("one_loop", True), ("all_118_loops", False)):
+        g = K.build_direct_graph(one)
+        G = L.Graph(device=device)
+        G.add_vertices(g["states"], g["fixed"])
+        G.add_edges(g["v0"], g["v1"], g["meas"])
+        G.initialize()
+        G.optimize(2)
+        G.set_vertices(g["states"])
+        t0 = time.perf_counter()
+        n = G.optimize(100)
+        t_gpu = time.perf_counter() - t0
+        chi_gpu = G.stats()[-1].chi2_after
+        OG = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"])
+        t0 = time.perf_counter()
+        it, tr = OG.optimize(100)
+        t_cpu = time.perf_counter() - t0
+        out[name] = {"gpu_iters": n, "gpu_seconds": t_gpu, "gpu_chi2": chi_gpu,
+                     "cpu_iters": it, "cpu_seconds": t_cpu, "cpu_chi2": tr[-1].chi2_after,
+                     "cpu_cores": 1, "speedup": t_cpu / t_gpu,
+                     "gpu_lm_iters_per_s": n / t_gpu, "cpu_lm_iters_per_s": it / t_cpu,
+                     "rmse_gpu_vs_cpu_m": synth.rmse(G.get_vertices(), OG.states),
+                     "linear_solver": "exact block Cholesky" if G.linear_solver_in_use() else "PCG"}
+        G.close()
+    return out
 
 
 def main():
@@ -106,6 +159,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched without torch.distributed.run: start the N ranks ourselves (before anything here
+        # has touched the GPU) and exit with their code -- never a silent 1-GPU number
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+               str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     if not torch.cuda.is_available():
@@ -123,7 +184,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sim3opt_amd import build as B, lib as L, synth
-    B.build()
+    if rank == 0:
+        B.build()  # one writer; the other ranks load the finished file
+    if dist is not None:
+        dist.barrier()
 
     # ---- workload (identical on every rank: same seeds) ----
     synth.DRIFT_TARGET = 0.05
@@ -324,12 +388,9 @@ def main():
                         "is ~1e8 and LM barely moves (DESIGN.md)"}
             R.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-            out["speedup_vs_cpu_edges_iters"] = out["edges_iters_per_s"] / out["cpu_baseline"]["value"]
-            ncpu = min(os.cpu_count() or 1, 16)
-            if ncpu > 1:  # for information: OpenMP over the per-edge loops (not the reference's model)
-                allc = cpu_baseline(args, threads=ncpu, budget_s=5.0)
-                out["cpu_baseline_all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "sample")}
+            out["cpu_baseline"] = cpu_baseline(args, g, out["ms_linearize_mean"], out["value"])
+            # configs both sides actually ran, in the reference's own configuration
+            out["kitti00_reference_configuration"] = kitti_table(local_rank)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
