@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WG) void k_amg_prolong(int nb, const int32_t* __res
                                                     const double* __restrict__ P,
                                                     const double* __restrict__ x_c,
                                                     const double* x_in, double* x_out,
-                                                    const DevScalars* __restrict__ sc) {
+                                                    const DevScalars* __restrict__ sc, double scale) {
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WG) void k_amg_prolong(int nb, const int32_t* __res
         if (act) add += P[(size_t)49 * row + rr + 7 * m] * xm;
       }
     }
-    if (act) x_out[(size_t)7 * row + rr] = x_in[(size_t)7 * row + rr] + add;
+    if (act) x_out[(size_t)7 * row + rr] = x_in[(size_t)7 * row + rr] + scale * add;
   }
 }
 

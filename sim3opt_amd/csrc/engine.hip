@@ -408,11 +408,13 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
                                                double* __restrict__ vals, double lambda,
                                                double* __restrict__ Minv, DevScalars* sc,
                                                double omega, const double* __restrict__ diagH,
-                                               const double* __restrict__ W) {
+                                               const double* __restrict__ W,
+                                               float* __restrict__ vals32 = nullptr) {
   const int row = r0 + blockIdx.x * WG + threadIdx.x;
   if (row >= r1) return;
   double a[7][7];
   double* blk = vals + (size_t)49 * rowptr[row];
+  float* blk32 = vals32 ? vals32 + (size_t)49 * rowptr[row] : nullptr;
   const double* src = diagH ? diagH + (size_t)49 * row : blk;
 #pragma unroll
   for (int c = 0; c < 7; ++c)
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
       for (int r = 0; r < 7; ++r) {
         a[r][c] += lambda * w[7 * c + r];
         blk[7 * c + r] = a[r][c];
+        if (blk32) blk32[7 * c + r] = (float)a[r][c];
       }
   } else {
 #pragma unroll
@@ -458,6 +461,13 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
     for (int c = 0; c < 7; ++c) dst[7 * r + c] = omega * a[r][c];
 }
 
+// FP32 copy of a block array (the multigrid's matrix passes read it)
+__global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restrict__ src,
+                                               float* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+    dst[i] = (float)src[i];
+}
+
 #include "amg_kernels.hpp"
 #include "direct_kernels.hpp"
 
@@ -484,11 +494,14 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 // MODE 3 (coarse multigrid levels): MODE 2 applied to p + xc[agg] -- the piecewise-constant
 // prolongation of the coarser level's correction is added while the input vector is gathered
 // (xc through `partials_r`, which the non-PCG modes do not use).
-template <int CH, bool NT, int MODE>
+// VT = float: the multigrid preconditioner's matrix passes stream an FP32 copy of the blocks (half
+// the bytes; vectors, accumulation and the smoother inverses stay FP64) -- the PCG's own SpMV
+// (MODE 0) always reads the FP64 blocks.
+template <int CH, bool NT, int MODE, typename VT = double>
 __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
-                                                  const double* __restrict__ vals,
+                                                  const VT* __restrict__ vals,
                                                   const double* __restrict__ p,
                                                   double* __restrict__ q, double lambda,
                                                   double* __restrict__ partials,
@@ -496,7 +509,8 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
                                                   double* __restrict__ partials_r,
                                                   DevScalars* __restrict__ sc,
                                                   const double* __restrict__ Minv, int lam_sc,
-                                                  const int32_t* __restrict__ agg) {
+                                                  const int32_t* __restrict__ agg,
+                                                  double xc_scale) {
   __shared__ double sh[4];
   if (sc) {
     if (sc->done) return;
@@ -564,20 +578,20 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
     int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
     int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
     double acc = 0.0;
-    double vc[CH], vn[CH];
+    VT vc[CH], vn[CH];
     double xgc, xgn = 0.0;
     // prologue: chunk at kbeg
     {
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int kk = kbeg + u < kend ? kbeg + u : kend - 1;
-        const double* vp = vals + (size_t)49 * kk + l49;
+        const VT* vp = vals + (size_t)49 * kk + l49;
         vc[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
       }
       const int kk = kbeg + gu < kend ? kbeg + gu : kend - 1;
       const int colu = __shfl(cv, kk - cbase);
       xgc = p[(size_t)7 * colu + gc];
-      if (MODE == 3) xgc += partials_r[(size_t)7 * agg[colu] + gc];
+      if (MODE == 3) xgc += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
     }
     row_begin(row, 0, xgc);
     for (int k = kbeg; k < kend; k += CH) {
@@ -591,13 +605,13 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int kk = kn + u < kend ? kn + u : kend - 1;
-          const double* vp = vals + (size_t)49 * kk + l49;
+          const VT* vp = vals + (size_t)49 * kk + l49;
           vn[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
         }
         const int kk = kn + gu < kend ? kn + gu : kend - 1;
         const int colu = __shfl(cv, kk - cbase);
         xgn = p[(size_t)7 * colu + gc];
-        if (MODE == 3) xgn += partials_r[(size_t)7 * agg[colu] + gc];
+        if (MODE == 3) xgn += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
             }
             k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
           }
-          acc += vc[u] * __shfl(xgc, 7 * u + c49);
+          acc += (double)vc[u] * __shfl(xgc, 7 * u + c49);
         }
       }
 #pragma unroll
@@ -1010,6 +1024,7 @@ class Engine {
     int32_t *rowptr = nullptr, *colidx = nullptr, *wrow = nullptr;
     int span_grid = 0;
     double *vals = nullptr, *diagH = nullptr, *W = nullptr, *Minv = nullptr;
+    float* vals32 = nullptr;  // FP32 copy of vals for the cycle's matrix passes (amg_fp32)
     int32_t *agg = nullptr, *mptr = nullptr, *mem = nullptr, *gptr = nullptr, *gblk = nullptr, *grow = nullptr;
     double *r = nullptr, *x = nullptr, *t = nullptr;  // level right-hand side, iterate, residual / result
   };
@@ -1021,6 +1036,11 @@ class Engine {
   double amg_omega = 0.9;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
   int amg_visits[AMG_MAX_LEVELS + 1];  // cycles spent on level l per visit of level l-1 (1 = V, 2 = W)
   bool amg_additive = false;           // level 0 additive: no fine-level matrix pass in the cycle
+  bool amg_fp32 = true;                // the cycle's matrix passes stream FP32 copies of the blocks
+  // over-correction: the coarse correction prolonged INTO level l is scaled by amg_over_l[l]
+  // (piecewise-constant prolongation under-estimates the correction; Stueben / Blaheta)
+  double amg_over_l[AMG_MAX_LEVELS + 1];
+  double amg_over = 1.0;               // (the factor of the launch being issued)
   int amg_status = 0;                  // first collective error inside a cycle
   std::string amg_err;
   // exact sparse block Cholesky (direct.hpp, direct_kernels.hpp): LinearSolverEigen's role on
@@ -1326,6 +1346,22 @@ class Engine {
       }
     }
     if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_FP32")) amg_fp32 = std::atoi(ev) != 0;
+    // measured on config 3: 1.8 into level 0 and 1.4 below cut the PCG iterations
+    // from 56 to 43 per solve; 2.0 (the limit for an exact coarse solve) is no better
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_over_l[l] = l == 0 ? 1.8 : 1.4;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_OVER")) {  // "a0[,a1[,a2...]]": last value repeats
+      double last = 1.0;
+      const char* p = ev;
+      for (int l = 0; l <= AMG_MAX_LEVELS; ++l) {
+        if (p && *p) {
+          last = std::max(0.5, std::min(3.0, std::atof(p)));
+          p = std::strchr(p, ',');
+          if (p) ++p;
+        }
+        amg_over_l[l] = last;
+      }
+    }
     std::string why;
     if (!build_amg_hierarchy(nb, s.rowptr.data(), s.colidx.data(), amg_host, why)) {
       if (opt.verbose) std::fprintf(stderr, "sim3opt: no multigrid hierarchy (%s)\n", why.c_str());
@@ -1377,6 +1413,10 @@ class Engine {
         AMGCHK(amg_alloc(L.r, (size_t)7 * L.nb, err));
         AMGCHK(amg_alloc(L.x, (size_t)7 * L.nb, err));
         AMGCHK(amg_alloc(L.t, (size_t)7 * L.nb, err));
+      }
+      if (amg_fp32) {
+        HIPCHK(hipMalloc((void**)&L.vals32, sizeof(float) * 49 * (size_t)std::max<int64_t>(L.nnzb, 1)));
+        amg_owned.push_back(L.vals32);
       }
       if (l + 1 < nl) {
         AMGCHK(amg_up(L.agg, h.agg, err));
@@ -1431,6 +1471,12 @@ class Engine {
       hipLaunchKernelGGL(k_amg_copydiag, dim3(grid_for(49 * (int64_t)Cc.nb, WG)), dim3(WG), 0, stream,
                          Cc.nb, Cc.rowptr, Cc.vals, Cc.diagH);
     }
+    if (amg_fp32)
+      for (int l = 0; l < nl; ++l) {
+        const size_t cnt = (size_t)49 * (size_t)amg[l].nnzb;
+        hipLaunchKernelGGL(k_to_f32, dim3(grid_for((int64_t)(cnt / 4), WG)), dim3(WG), 0, stream, cnt,
+                           (const double*)amg[l].vals, amg[l].vals32);
+      }
     HIPCHK(hipGetLastError());
     amg_stale = false;
     return SIM3OPT_OK;
@@ -1444,7 +1490,7 @@ class Engine {
       const int lo = l == 0 ? r0 : 0, hi = l == 0 ? r1 : L.nb;  // level 0 is row-partitioned
       hipLaunchKernelGGL(k_jacobi, dim3(std::max(1, (hi - lo + WG - 1) / WG)), dim3(WG), 0, stream, lo, hi,
                          L.rowptr, L.vals, lambda, L.Minv, d_sc, l == 0 && amg_additive ? 1.0 : amg_omega,
-                         L.diagH, L.W);
+                         L.diagH, L.W, l > 0 ? L.vals32 : (float*)nullptr);
     }
     // dense inverse of the coarsest level: one launch per 14-row pivot block, buffers ping-pong
     const AmgLevel& Lc = amg[nl - 1];
@@ -1482,9 +1528,20 @@ class Engine {
   hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
                      L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, (double*)nullptr, rvec,     \
                      const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
-                     (const int32_t*)L.agg)
-    if (level == 0) { if (mode == 1) AMG_SPMV(true, 1); else AMG_SPMV(true, 2); }
-    else { if (mode == 1) AMG_SPMV(false, 1); else if (mode == 3) AMG_SPMV(false, 3); else AMG_SPMV(false, 2); }
+                     (const int32_t*)L.agg, amg_over)
+#define AMG_SPMV32(NTV, MODEV)                                                                    \
+  hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
+                     L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0,         \
+                     (double*)nullptr, rvec, const_cast<double*>(xc),                               \
+                     level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over)
+    if (amg_fp32) {
+      if (level == 0) { if (mode == 1) AMG_SPMV32(true, 1); else AMG_SPMV32(true, 2); }
+      else { if (mode == 1) AMG_SPMV32(false, 1); else if (mode == 3) AMG_SPMV32(false, 3); else AMG_SPMV32(false, 2); }
+    } else {
+      if (level == 0) { if (mode == 1) AMG_SPMV(true, 1); else AMG_SPMV(true, 2); }
+      else { if (mode == 1) AMG_SPMV(false, 1); else if (mode == 3) AMG_SPMV(false, 3); else AMG_SPMV(false, 2); }
+    }
+#undef AMG_SPMV32
 #undef AMG_SPMV
   }
 
@@ -1513,10 +1570,10 @@ class Engine {
     const int gp = grid_for((F.nb + 8) / 9, 4);
     if (l == 0)
       hipLaunchKernelGGL((k_amg_prolong<true>), dim3(gp), dim3(WG), 0, stream, F.nb, F.agg, d_P, xc,
-                         xin, xout, (const DevScalars*)d_sc);
+                         xin, xout, (const DevScalars*)d_sc, amg_over);
     else
       hipLaunchKernelGGL((k_amg_prolong<false>), dim3(gp), dim3(WG), 0, stream, F.nb, F.agg,
-                         (const double*)nullptr, xc, xin, xout, (const DevScalars*)nullptr);
+                         (const double*)nullptr, xc, xin, xout, (const DevScalars*)nullptr, amg_over);
   }
 
   // Solves the level-(l+1) problem approximately (right-hand side amg[l+1].r, first iterate
@@ -1546,6 +1603,7 @@ class Engine {
     spmv_mode(F, 1, l, cur, other, F.r);
     amg_restrict(l, other);
     const double* xc = amg_coarse(l);
+    amg_over = amg_over_l[l];
     if (l == 0) {
       amg_prolong(l, xc, cur, cur);
       spmv_mode(F, 2, l, cur, other, F.r);
@@ -1569,7 +1627,9 @@ class Engine {
     }
     if (amg_additive) {
       amg_restrict(0, d_r);
-      amg_prolong(0, amg_coarse(0), d_z, d_az);
+      const double* xc0 = amg_coarse(0);
+      amg_over = amg_over_l[0];
+      amg_prolong(0, xc0, d_z, d_az);
     } else {
       amg_cycle(0, d_z, d_az);
     }
@@ -1734,11 +1794,11 @@ class Engine {
 #define SPAN_CASE(CH, NTV)                                                                       \
   hipExtLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb, \
                         d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,         \
-                        d_part_b, scp, (const double*)nullptr, 1, (const int32_t*)nullptr)
+                        d_part_b, scp, (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0)
 #define SPAN_PLAIN(CH, NTV)                                                                     \
   hipLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, nb, d_wrow,       \
                      d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp,     \
-                     (const double*)nullptr, 1, (const int32_t*)nullptr)
+                     (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0)
     if (!ev0) {  // plain launch: capturable into a hipGraph
       if (spmv_chunk <= 4) { if (spmv_nt) SPAN_PLAIN(4, true); else SPAN_PLAIN(4, false); }
       else { if (spmv_nt) SPAN_PLAIN(8, true); else SPAN_PLAIN(8, false); }
