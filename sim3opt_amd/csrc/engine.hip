@@ -1337,7 +1337,9 @@ class Engine {
     // times per visit; the additive level-0 form is a knob (about as fast on config 3, less robust
     // on ill-conditioned chains)
     amg_additive = false;
-    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = l <= 1 ? 1 : 3;
+    // round 2: with FP32 block copies the coarse levels are cheap enough for two visits of level 1
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_visits[l] = l <= 1 ? 2 : 3;
+    amg_visits[0] = 1;
     if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) {  // e.g. "122": visits of levels 1, 2, 3...
       int last = 1;
       for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
@@ -1347,9 +1349,10 @@ class Engine {
     }
     if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("SIM3OPT_AMG_FP32")) amg_fp32 = std::atoi(ev) != 0;
-    // measured on config 3: 1.8 into level 0 and 1.4 below cut the PCG iterations
-    // from 56 to 43 per solve; 2.0 (the limit for an exact coarse solve) is no better
-    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_over_l[l] = l == 0 ? 1.8 : 1.4;
+    // measured on config 3: 1.8 into level 0 and 1.6 below cut the PCG iterations of
+    // a solve from 56 to 43 (cycle 1/3) and from 29 to 25 (cycle 2/3); 2.0 (the limit for an exact
+    // coarse solve) is no better
+    for (int l = 0; l <= AMG_MAX_LEVELS; ++l) amg_over_l[l] = l == 0 ? 1.8 : 1.6;
     if (const char* ev = std::getenv("SIM3OPT_AMG_OVER")) {  // "a0[,a1[,a2...]]": last value repeats
       double last = 1.0;
       const char* p = ev;
