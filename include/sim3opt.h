@@ -226,9 +226,11 @@ int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels,
 /* ---- row-partitioned multi-GPU (one process per GPU, RCCL over xGMI) ----
  * Every rank adds the SAME full graph; rank r then owns a contiguous range of block rows (equal
  * length), linearises the edges incident to them, streams its rows in the SpMV and keeps
- * a replica of all vertex estimates.  Collectives per PCG iteration: one all-gather of the search
- * direction, two scalar all-reduces; per LM trial: one all-gather of the step, one 2-scalar
- * all-reduce.  All ranks return identical results.  Call between create and initialize.
+ * a replica of all vertex estimates.  Collectives per PCG iteration (single-reduction CG): ONE
+ * in-place all-gather of the preconditioned residual and ONE 2-double all-reduce; with the multigrid
+ * preconditioner a second all-gather and the all-reduce of the restricted level-1 residual
+ * (DESIGN.md section 7 lists sizes for N = 2 / 4 / 8); per LM trial: one all-gather of the step, one
+ * 2-double all-reduce.  All ranks return identical results.  Call between create and initialize.
  * unique_id is the 128-byte ncclUniqueId produced by sim3opt_comm_unique_id on rank 0 and broadcast
  * by the caller (torch.distributed / MPI). */
 int sim3opt_comm_unique_id(uint8_t id_out[128]);
@@ -243,6 +245,14 @@ typedef int (*sim3opt_allgatherv_fn)(void* ctx, double* buf, const int64_t* offs
 int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
                                 sim3opt_allreduce_fn allreduce, sim3opt_allgatherv_fn allgatherv,
                                 void* ctx);
+/* Plan of the per-iteration exchange for `n_block_rows` rows over `world` ranks (host only): fills
+ * row_begin (world+1, may be NULL) with the equal-length rank partition and returns 1 when the
+ * in-place equal-count ncclAllGather applies (always, for this partition -- trailing ranks may be
+ * short or empty), 0 otherwise, negative on bad arguments.  *count = doubles each rank contributes,
+ * *padded_len = doubles every exchanged vector is allocated with (world * count >= 7 n_block_rows;
+ * the tail is padding no kernel reads). */
+int sim3opt_comm_allgather_plan(int32_t n_block_rows, int32_t world, int32_t* row_begin,
+                                int64_t* count, int64_t* padded_len);
 /* host-side partition plans (no GPU needed), world+1 entries each:
  *   _equal : the RANK partition -- equal-length row spans, so the per-iteration exchange is one
  *            in-place ncclAllGather (pose-graph rows have near-uniform block counts)

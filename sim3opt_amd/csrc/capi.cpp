@@ -458,6 +458,17 @@ int sim3opt_partition_rows_equal(int32_t n_block_rows, int32_t world, int32_t* r
   return SIM3OPT_OK;
 }
 
+int sim3opt_comm_allgather_plan(int32_t n_block_rows, int32_t world, int32_t* row_begin,
+                                int64_t* count, int64_t* padded_len) {
+  if (n_block_rows < 0 || world < 1) return SIM3OPT_ERR_ARG;
+  std::vector<int32_t> rb(world + 1);
+  partition_rows_equal(n_block_rows, world, rb.data());
+  std::vector<int64_t> offs(world + 1);
+  for (int r = 0; r <= world; ++r) offs[r] = 7 * (int64_t)rb[r];
+  if (row_begin) std::memcpy(row_begin, rb.data(), sizeof(int32_t) * (size_t)(world + 1));
+  return allgather_equal_plan(offs.data(), world, count, padded_len) ? 1 : 0;
+}
+
 int sim3opt_comm_unique_id(uint8_t id_out[128]) {
   if (!id_out) return SIM3OPT_ERR_ARG;
   std::string err;

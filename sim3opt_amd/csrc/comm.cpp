@@ -142,15 +142,14 @@ int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t
   if (kind == 1) {
     // equal spans (the engine's partition; buffers are padded to world x count): ONE in-place
     // ncclAllGather -- rank r's segment already sits at recvbuff + r * count
-    const int64_t cnt = offs[1] - offs[0];
-    bool equal = cnt > 0;
-    for (int r = 0; r < world && equal; ++r) equal = offs[r] == (int64_t)r * cnt || offs[r] == offs[world];
-    if (equal) {
+    int64_t cnt = 0;
+    if (allgather_equal_plan(offs.data(), world, &cnt, nullptr)) {
       NCCLCHK(g_api.AllGather(dvec + (int64_t)rank * cnt, dvec, (size_t)cnt, ncclFloat64,
                               (ncclComm_t)nccl, stream));
       return SIM3OPT_OK;
     }
-    // general spans: one grouped broadcast per owner
+    // general spans (not produced by the engine's partition; kept for callers of the transport with
+    // their own split): one grouped broadcast per owner
     NCCLCHK(g_api.GroupStart());
     for (int r = 0; r < world; ++r) {
       const size_t cnt = (size_t)(offs[r + 1] - offs[r]);

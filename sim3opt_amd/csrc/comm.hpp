@@ -1,7 +1,7 @@
 // comm.hpp -- collectives of the row-partitioned multi-GPU path (one process per GPU).
 //
 // Two transports behind one interface:
-//   RCCL      ncclAllReduce / grouped ncclBroadcast on the engine's HIP stream (xGMI); librccl is
+//   RCCL      in-place ncclAllReduce / ncclAllGather on the engine's HIP stream (xGMI); librccl is
 //             dlopen'ed at sim3opt_comm_init so that libsim3opt.so loads on machines without it
 //   callbacks host-staged: the engine copies the operands to pinned host memory and calls the
 //             user's functions (MPI, torch.distributed/gloo, ...).  Used by the 2-process tests.
@@ -39,6 +39,20 @@ struct Comm {
                  std::string& err);
   void release();
 };
+
+// Plan of the in-place all-gather of a vector split at offs[0..world] (in doubles): true when the
+// spans are the engine's equal-count partition -- offs[r] = r * count, trailing ranks short or empty
+// -- so that ONE ncclAllGather of `count` doubles per rank does the exchange; the buffer must then
+// hold `padded_len` = world * count doubles (>= offs[world]: the tail beyond the vector is padding
+// that no kernel reads).
+inline bool allgather_equal_plan(const int64_t* offs, int32_t world, int64_t* count, int64_t* padded_len) {
+  const int64_t cnt = offs[1] - offs[0];
+  bool equal = cnt > 0;
+  for (int r = 0; r < world && equal; ++r) equal = offs[r] == (int64_t)r * cnt || offs[r] == offs[world];
+  if (count) *count = cnt;
+  if (padded_len) *padded_len = equal ? (int64_t)world * cnt : offs[world];
+  return equal;
+}
 
 int comm_unique_id(uint8_t id_out[128], std::string& err);
 int comm_init_rccl(Comm& c, int32_t rank, int32_t world, const uint8_t id[128], std::string& err);

@@ -1234,7 +1234,9 @@ class Engine {
     double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q, &d_s};
     for (double** v : vecs) {
       // padded to world x (7 x rows per rank) so the all-gather can run in place with equal counts
-      const size_t n_alloc = std::max<size_t>((size_t)n, (size_t)comm.world * (size_t)(offs[1] - offs[0]));
+      int64_t padded = 0;
+      (void)allgather_equal_plan(offs.data(), comm.world, nullptr, &padded);
+      const size_t n_alloc = std::max<size_t>((size_t)n, (size_t)padded);
       HIPCHK(hipMalloc((void**)v, sizeof(double) * n_alloc));
       HIPCHK(hipMemset(*v, 0, sizeof(double) * n_alloc));
     }
@@ -1393,7 +1395,9 @@ class Engine {
     L0.rowptr = d_rowptr; L0.colidx = d_colidx; L0.wrow = d_wrow; L0.span_grid = span_grid;
     L0.vals = d_vals; L0.Minv = d_Minv; L0.r = d_r; L0.x = d_z;
     // (padded like the PCG vectors: the multi-GPU all-gather runs in place with equal counts)
-    AMGCHK(amg_alloc(d_az, std::max<size_t>((size_t)n, (size_t)comm.world * (size_t)(offs[1] - offs[0])), err));
+    int64_t padded = 0;
+    (void)allgather_equal_plan(offs.data(), comm.world, nullptr, &padded);
+    AMGCHK(amg_alloc(d_az, std::max<size_t>((size_t)n, (size_t)padded), err));
     AMGCHK(amg_alloc(d_P, (size_t)49 * nb, err));
     AMGCHK(amg_up(d_row2v, s.row2vertex, err));
     L0.t = d_az;
@@ -1960,7 +1964,15 @@ class Engine {
                              d_Minv, d_Gm, d_r, d_z, (const DevScalars*)d_sc);
         if (use_mg) (void)amg_apply(err);  // single GPU here: no collectives inside
       }
-      HIPCHK(hipStreamEndCapture(stream, &gr));
+      {  // (a failed launch inside the region must not leave the stream capturing)
+        const hipError_t le = hipGetLastError();
+        const hipError_t ce = hipStreamEndCapture(stream, &gr);
+        if (le != hipSuccess || ce != hipSuccess) {
+          if (gr) (void)hipGraphDestroy(gr);
+          err = std::string("PCG graph capture: ") + hipGetErrorString(le != hipSuccess ? le : ce);
+          return SIM3OPT_ERR_HIP;
+        }
+      }
       HIPCHK(hipGraphInstantiate(&pcg_graph, gr, nullptr, nullptr, 0));
       (void)hipGraphDestroy(gr);
       pcg_graph_kind = prec;

@@ -110,6 +110,8 @@ SYMBOLS = {
     "sim3opt_linear_solver_in_use": (C.c_int, [_vp]),
     "sim3opt_direct_plan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), _ip, _ip, _ip, _ip, _ip, _ip,
                                       _ip, _ip, _ip, _ip]),
+    "sim3opt_comm_allgather_plan": (C.c_int, [C.c_int32, C.c_int32, _ip, C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_int64)]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),

@@ -148,6 +148,32 @@ def test_partition_rows_balances_blocks():
     assert beg[0] == 0 and beg[-1] == 1 and np.all(np.diff(beg) >= 0)
 
 
+def test_allgather_plan_for_uneven_and_empty_ranks():
+    """The multi-GPU exchange is ONE in-place equal-count ncclAllGather: the library's own predicate
+    and buffer sizing (comm.hpp allgather_equal_plan, used by the RCCL transport and by the engine's
+    allocations), for row counts that do not divide by the rank count and for ranks left empty."""
+    import ctypes as C
+    lib = L.load()
+    for nb in (1, 2, 3, 7, 8, 9, 63, 64, 770, 99999, 100000):
+        for world in (1, 2, 3, 4, 5, 8):
+            rb = np.zeros(world + 1, dtype=np.int32)
+            cnt, padded = C.c_int64(), C.c_int64()
+            rc = lib.sim3opt_comm_allgather_plan(nb, world, rb.ctypes.data_as(L._ip), C.byref(cnt),
+                                                 C.byref(padded))
+            assert rc == 1, (nb, world)  # the equal-count path always applies to this partition
+            rpr = -(-nb // world)
+            assert rb[0] == 0 and rb[-1] == nb and np.all(np.diff(rb) >= 0)
+            assert all(int(rb[r + 1] - rb[r]) in (rpr, nb - min(r * rpr, nb)) or rb[r + 1] == rb[r]
+                       for r in range(world))
+            assert cnt.value == 7 * rpr and padded.value == 7 * rpr * world >= 7 * nb
+            # rank r's segment sits at r * count inside the padded buffer; empty trailing ranks own
+            # padding only, and no owned segment reaches into another rank's slot
+            for r in range(world):
+                lo, hi = 7 * int(rb[r]), 7 * int(rb[r + 1])
+                assert lo == min(r * cnt.value, 7 * nb) and hi - lo <= cnt.value
+    assert lib.sim3opt_comm_allgather_plan(-1, 2, None, None, None) < 0
+
+
 def test_umeyama_alignment_and_kitti_original_map_rmse():
     """Evaluation harness (kitti_surf.cpp:1091-1161, :1427-1463): C++ Umeyama vs numpy SVD, and
     the RMSE of the un-optimised VO keyframe trajectory against KITTI-00 ground truth."""
