@@ -5,7 +5,8 @@ import csv, json, sys
 acc = {}
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]
-    if "k_spmv_span" not in name or ", 0>" not in name.split("(")[0]:
+    head = name.split("(")[0]
+    if "k_spmv_span" not in head or not (", 0>" in head or ", 0, double>" in head):
         continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = acc.setdefault(name.split("(")[0], dict(all_n=0, all_us=0.0, work_n=0, work_us=0.0))
