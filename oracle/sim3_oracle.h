@@ -15,8 +15,12 @@
  * tests/test_oracle.py: the reference's input data files, the by-construction
  * zero residual of odometry edges (kitti_surf.cpp:653-666), the loop scale
  * ln(5.32393351) (loopConstraints.txt record 1), group identities, closed-form
- * Jacobians, dense numpy linear algebra, and an independent numpy restatement of
- * the Sim(3) formulae (sim3opt_amd/sim3np.py, used only to prepare data).
+ * Jacobians, dense numpy linear algebra, an independent numpy restatement of
+ * the Sim(3) formulae (sim3opt_amd/sim3np.py, used only to prepare data), and --
+ * for the LM trace itself -- an independent numpy / scipy Levenberg-Marquardt
+ * (tests/golden/make_lm_golden.py: own central differences, scipy assembly,
+ * SuperLU solve, own lambda policy) whose lock-step and free-run records on both
+ * KITTI-00 graphs are committed as tests/golden/kitti_lm_golden.json.
  */
 #ifndef SIM3_ORACLE_H
 #define SIM3_ORACLE_H
