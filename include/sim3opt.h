@@ -209,12 +209,17 @@ int sim3opt_linear_solver_in_use(const sim3opt_graph* g);
  * src[srcptr[s]..srcptr[s+1]) (indices into the block-CSR values of sim3opt_get_system) and subtracts
  * L[pa[k]] L[pb[k]]^T for k in pairptr[s]..pairptr[s+1].  Schedule: group q runs levels
  * gptr[q]..gptr[q+1], level l is columns lcolp[l]..lcolp[l+1]; groups but the last are independent.
+ * Work split of the kernel: level l runs in rounds rptr[l]..rptr[l+1]; round q is 18 ints at
+ * cells[18 q]: wavefront w owns blocks cells[18 q + w]..cells[18 q + w + 1] (at most 8) and the
+ * products cells[18 q + 9 + w]..cells[18 q + 9 + w + 1] (4 wavefronts in the bottom groups, 8 in
+ * the last one).
  * dims = {columns, blocks of L, block products per factorisation, elimination-tree height, groups,
- * levels, entries of src, 0}.  Two calls: arrays NULL to size them, then filled.  max_pairs <= 0: the
- * automatic limit.  SIM3OPT_ERR_STATE when a factorisation needs more block products than that. */
+ * levels, entries of src, rounds}.  Two calls: arrays NULL to size them, then filled.  max_pairs <= 0:
+ * the automatic limit.  SIM3OPT_ERR_STATE when a factorisation needs more block products than that. */
 int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], int32_t* perm,
                         int32_t* colptr, int32_t* lrow, int32_t* srcptr, int32_t* src,
-                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp);
+                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp,
+                        int32_t* rptr, int32_t* cells);
 /* Structure of the multigrid hierarchy `preconditioner = 2` would use for this graph (host only, no
  * GPU needed, may be called before initialize): *n_levels levels; rows[l] / blocks[l] = block rows
  * and stored 7x7 blocks of level l (up to `capacity` levels are written); aggregate_of_row (may be

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(WG) void k_amg_adjoint(int nb, const int32_t* __res
 
 // Coarse block cb = sum over its fine blocks k (row i, column j) of P_i^T A_k P_j, in list order.
 // One wavefront per coarse block; the two 7x7x7 products run on the LDS crossbar (ds_bpermute).
+// Every fine block is read exactly once here, so the FP32 copy the cycle's matrix passes stream
+// (vals32_f, may be null) is written on the way.  Four fine blocks (and their P_i, P_j) in flight.
 template <bool HASP>
 __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ gblk,
@@ -60,7 +62,8 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
                                                      const int32_t* __restrict__ colidx_f,
                                                      const double* __restrict__ vals_f,
                                                      const double* __restrict__ P,
-                                                     double* __restrict__ vals_c) {
+                                                     double* __restrict__ vals_c,
+                                                     float* __restrict__ vals32_f) {
   const int lane = threadIdx.x & 63;
   const int cb = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (cb >= ncb) return;
@@ -68,23 +71,36 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
   const int r = l49 % 7, c = l49 / 7;
   double acc = 0.0;
   const int e0 = gptr[cb], e1 = gptr[cb + 1];
-  for (int e = e0; e < e1; ++e) {
-    const int k = gblk[e];
-    const double a = vals_f[(size_t)49 * k + l49];
-    if (HASP) {
-      const int i = grow[e], j = colidx_f[k];
-      const double pi = P[(size_t)49 * i + l49];
-      const double pj = P[(size_t)49 * j + l49];
-      double t = 0.0;  // T = A P_j
+  for (int e = e0; e < e1; e += 4) {
+    const int m = e1 - e < 4 ? e1 - e : 4;
+    int kk[4];
+    double av[4], piv[4], pjv[4];
 #pragma unroll
-      for (int m = 0; m < 7; ++m) t += __shfl(a, r + 7 * m) * __shfl(pj, m + 7 * c);
-      double o = 0.0;  // P_i^T T
+    for (int u = 0; u < 4; ++u)
+      if (u < m) {
+        kk[u] = gblk[e + u];
+        av[u] = vals_f[(size_t)49 * kk[u] + l49];
+        if (HASP) {
+          piv[u] = P[(size_t)49 * grow[e + u] + l49];
+          pjv[u] = P[(size_t)49 * colidx_f[kk[u]] + l49];
+        }
+      }
 #pragma unroll
-      for (int m = 0; m < 7; ++m) o += __shfl(pi, m + 7 * r) * __shfl(t, m + 7 * c);
-      acc += o;
-    } else {
-      acc += a;
-    }
+    for (int u = 0; u < 4; ++u)
+      if (u < m) {
+        if (vals32_f && lane < 49) vals32_f[(size_t)49 * kk[u] + lane] = (float)av[u];
+        if (HASP) {
+          double t = 0.0;  // T = A P_j
+#pragma unroll
+          for (int q = 0; q < 7; ++q) t += __shfl(av[u], r + 7 * q) * __shfl(pjv[u], q + 7 * c);
+          double o = 0.0;  // P_i^T T
+#pragma unroll
+          for (int q = 0; q < 7; ++q) o += __shfl(piv[u], q + 7 * r) * __shfl(t, q + 7 * c);
+          acc += o;
+        } else {
+          acc += av[u];
+        }
+      }
   }
   if (lane < 49) vals_c[(size_t)49 * cb + lane] = acc;
 }

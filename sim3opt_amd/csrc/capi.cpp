@@ -398,7 +398,8 @@ int sim3opt_linear_solver_in_use(const sim3opt_graph* g) {
 
 int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], int32_t* perm,
                         int32_t* colptr, int32_t* lrow, int32_t* srcptr, int32_t* src,
-                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp) {
+                        int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp,
+                        int32_t* rptr, int32_t* cells) {
   if (!g || !dims) return fail(g, SIM3OPT_ERR_ARG, "direct_plan: bad argument");
   Structure st;
   if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
@@ -410,12 +411,14 @@ int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], in
     return SIM3OPT_ERR_STATE;
   }
   dims[0] = P.nb; dims[1] = P.nL; dims[2] = P.npairs; dims[3] = P.height; dims[4] = P.ngroups();
-  dims[5] = (int64_t)P.lcolp.size() - 1; dims[6] = (int64_t)P.src.size(); dims[7] = 0;
+  dims[5] = (int64_t)P.lcolp.size() - 1; dims[6] = (int64_t)P.src.size();
+  dims[7] = (int64_t)P.cells.size() / DirectPlan::CELL_STRIDE;
   auto out = [](int32_t* dst, const std::vector<int32_t>& v) {
     if (dst && !v.empty()) std::memcpy(dst, v.data(), sizeof(int32_t) * v.size());
   };
   out(perm, P.perm); out(colptr, P.colptr); out(lrow, P.lrow); out(srcptr, P.srcptr); out(src, P.src);
   out(pairptr, P.pairptr); out(pa, P.pa); out(pb, P.pb); out(gptr, P.gptr); out(lcolp, P.lcolp);
+  out(rptr, P.rptr); out(cells, P.cells);
   return SIM3OPT_OK;
 }
 

@@ -154,8 +154,9 @@ bool symbolic(int32_t nb, const std::vector<int32_t>& aptr, const std::vector<in
 }  // namespace
 
 bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int64_t max_pairs,
-                       int32_t subtree_cols, DirectPlan& P, std::string& why) {
+                       int32_t subtree_cols, DirectPlan& P, std::string& why, int32_t sub_waves) {
   P = DirectPlan();
+  P.sub_waves = std::max(1, std::min((int)DirectPlan::CELL_WAVES, (int)sub_waves));
   if (nb <= 0) { why = "empty system"; return false; }
   // adjacency without the diagonal and without repeated columns
   std::vector<int32_t> aptr(nb + 1, 0), adj;
@@ -308,6 +309,7 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
       for (int64_t s = 0; s < P.nL; ++s) P.pairptr[s + 1] += P.pairptr[s];
       P.pa.resize(P.pairptr[P.nL]);
       P.pb.resize(P.pairptr[P.nL]);
+      P.pcol.resize(P.pairptr[P.nL]);
       cur.assign(P.pairptr.begin(), P.pairptr.end() - 1);
     }
     for (int32_t k = 0; k < nb; ++k) {
@@ -321,9 +323,53 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
           else {
             P.pa[cur[s]] = base + (int32_t)b;
             P.pb[cur[s]] = base + (int32_t)a;
+            P.pcol[cur[s]] = k;
             ++cur[s];
           }
         }
+    }
+  }
+  // ---- work split: rounds of cells per level (see direct.hpp) ----
+  {
+    const int NW = DirectPlan::CELL_WAVES, CS = DirectPlan::CELL_SLOTS, ST = DirectPlan::CELL_STRIDE;
+    P.rptr.assign(1, 0);
+    for (int32_t g = 0; g < P.ngroups(); ++g) {
+      const int nw = g == P.ngroups() - 1 ? NW : P.sub_waves;
+      for (int32_t l = P.gptr[g]; l < P.gptr[g + 1]; ++l) {
+        const int32_t S0 = P.colptr[P.lcolp[l]], S1 = P.colptr[P.lcolp[l + 1]];
+        // weight of a block = its products + 2, a diagonal block + DIAGW (its 7x7 Cholesky and
+        // inverse run in a single lane: about as long as a dozen products)
+        const int64_t DIAGW = 12;
+        auto weight = [&](int32_t s) {
+          return (int64_t)(P.pairptr[s + 1] - P.pairptr[s]) + 2 + (P.lrow[s] == P.lcol[s] ? DIAGW : 0);
+        };
+        int64_t W = 0;
+        for (int32_t s = S0; s < S1; ++s) W += weight(s);
+        const int64_t R0 = std::max<int64_t>(1, ((int64_t)(S1 - S0) + (int64_t)CS * nw - 1) / ((int64_t)CS * nw));
+        const int64_t target = (W + R0 * nw - 1) / (R0 * nw);
+        std::vector<int32_t> bounds(1, S0);  // cell boundaries, in order (round-major, wave-minor)
+        int64_t cw = 0;
+        int cnt = 0;
+        for (int32_t s = S0; s < S1; ++s) {
+          cw += weight(s);
+          ++cnt;
+          if (cw >= target || cnt == CS) { bounds.push_back(s + 1); cw = 0; cnt = 0; }
+        }
+        if (bounds.back() != S1) bounds.push_back(S1);
+        const size_t ncell = bounds.size() - 1;
+        const size_t R = std::max<size_t>(1, (ncell + nw - 1) / nw);
+        for (size_t q = 0; q < R; ++q) {
+          const size_t base = P.cells.size();
+          P.cells.resize(base + ST, S1);
+          for (int w = 0; w <= NW; ++w) {
+            const size_t c = q * nw + (size_t)std::min(w, nw);
+            const int32_t sb = c < bounds.size() ? bounds[c] : S1;
+            P.cells[base + w] = sb;
+            P.cells[base + NW + 1 + w] = P.pairptr[sb];
+          }
+        }
+        P.rptr.push_back((int32_t)(P.cells.size() / ST));
+      }
     }
   }
   return true;

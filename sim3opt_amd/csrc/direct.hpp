@@ -39,10 +39,21 @@ struct DirectPlan {
   std::vector<int32_t> src;       //   summed into this block of L (parallel edges: several; fill: none)
   std::vector<int32_t> pairptr;   // nL + 1 -> pa/pb: products L[pa] L[pb]^T subtracted from this
   std::vector<int32_t> pa, pb;    //   block, ascending source column
+  std::vector<int32_t> pcol;      //   ... and that source column k (the forward solve rides along)
   // schedule: group g runs levels [gptr[g], gptr[g+1]); level l is columns [lcolp[l], lcolp[l+1]).
   // The last group is the top of the tree (everything the others feed into).
   std::vector<int32_t> gptr;
   std::vector<int32_t> lcolp;
+  // work split of the factorisation kernel: level l is done in rounds [rptr[l], rptr[l+1]); in round
+  // q wavefront w owns the contiguous blocks cells[CELL_STRIDE q + w] .. cells[CELL_STRIDE q + w + 1]
+  // (at most CELL_SLOTS of them, balanced by their product counts) and their products
+  // cells[CELL_STRIDE q + CELL_WAVES + 1 + w] .. [.. + w + 1] -- one scalar read tells a wavefront
+  // everything it needs to issue its index loads.  Bottom groups run `sub_waves` wavefronts, the top
+  // group CELL_WAVES.
+  static constexpr int CELL_WAVES = 8, CELL_SLOTS = 8, CELL_STRIDE = 2 * (CELL_WAVES + 1);
+  int32_t sub_waves = 4;
+  std::vector<int32_t> rptr;
+  std::vector<int32_t> cells;
   int32_t ngroups() const { return (int32_t)gptr.size() - 1; }
 };
 
@@ -51,7 +62,8 @@ struct DirectPlan {
 // need more than max_pairs block products -- the graph is then left to the PCG.
 // subtree_cols: bottom subtrees of at most this many columns become independent groups
 // (<= 0: automatic).
+// sub_waves: wavefronts per workgroup of the bottom groups (1 .. CELL_WAVES).
 bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int64_t max_pairs,
-                       int32_t subtree_cols, DirectPlan& plan, std::string& why);
+                       int32_t subtree_cols, DirectPlan& plan, std::string& why, int32_t sub_waves = 4);
 
 }  // namespace sim3opt

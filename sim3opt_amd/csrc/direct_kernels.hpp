@@ -5,13 +5,18 @@
 //
 // Left-looking by levels of the elimination tree; a level is a contiguous range of columns and of
 // stored blocks (direct.hpp).  One workgroup owns one group of the schedule and walks its levels
-// with workgroup barriers; within a level
-//   phase A  wavefront per stored block (i,j): sum of its H blocks (+ lambda on the diagonal) minus
-//            the listed products L(i,k) L(j,k)^T, in list order; the diagonal block also gathers
-//            b_j - sum_k L(j,k) y_k (the forward solve rides along)
-//   phase B  wavefront per column: 7x7 Cholesky of the diagonal block, its inverse, y_j
-//   phase C  wavefront per off-diagonal block: L(i,j) = raw(i,j) L(j,j)^-T
-// and the backward solve walks the levels downwards, a wavefront per column.
+// with workgroup barriers.  A factorisation is a few MFLOP: what it costs is dependent memory
+// round trips, so a level is organised to need few of them --
+//   * once per linearisation k_ldl_gather sums every block's source blocks of H into `Aperm` and
+//     permutes b: a trial starts from there (+ lambda on the diagonal), without index chains;
+//   * the host split every level into rounds of cells (direct.hpp): ONE scalar read gives a
+//     wavefront its contiguous blocks and products; the product indices of a cell arrive by one
+//     vector load (lane = product), the operands of up to 8 products are requested together;
+//   * phase A+B  per block in turn: raw = Aperm (+ lambda) - sum of the listed L(i,k) L(j,k)^T in
+//     list order; a diagonal block is factored right away (7x7 Cholesky and inverse through LDS,
+//     forward solve y_j riding along), an off-diagonal block waits in LDS;
+//   * barrier; phase C: off-diagonal blocks times L(j,j)^-T; barrier.
+// The backward solve walks the levels downwards, a wavefront per column.
 // Lane l of a wavefront holds entry l49 = l mod 49 of a column-major 7x7 block (lanes 49..63 mirror
 // lanes 0..14: every lane issues a valid load); 7x7x7 products go through the LDS crossbar
 // (ds_bpermute).  No atomics, fixed summation order: bit-reproducible.
@@ -28,21 +33,32 @@ struct LdlArgs {
   const int32_t* pairptr;
   const int32_t* pa;
   const int32_t* pb;
+  const int32_t* pcol;
   const int32_t* gptr;
   const int32_t* lcolp;
+  const int32_t* rptr;
+  const int32_t* cells;
   const double* vals;  // block-CSR values of H (column-major 7x7)
   const double* b;     // right-hand side, block rows of H
+  double* Aperm;       // nL x 49: blocks of H in the layout of L (no damping)
+  double* bp;          // 7 nb: b in elimination order
   double* L;           // nL x 49
   double* Dinv;        // nb x 49: L(j,j)^-1 (lower triangular, column-major)
   double* y;           // 7 nb, elimination order
   double* xp;          // 7 nb, elimination order
   double* x;           // 7 nb, block rows of H (the result)
+  int32_t nb, nL;
   double lambda;
   DevScalars* sc;
+  long long* dbg;  // tuning aid (SIM3OPT_DIRECT_TRACE): wall_clock64 stamps of the top group's levels
 };
 
-constexpr int LDL_WG_TOP = 1024;  // the top of the tree: one workgroup of 16 wavefronts
-constexpr int LDL_WG_SUB = 256;   // bottom subtrees: one workgroup of 4 wavefronts each
+constexpr int LDL_WG_TOP = 64 * DirectPlan::CELL_WAVES;  // the top of the tree: one workgroup of 8
+// wavefronts (512 threads leave each wavefront 256 VGPRs: with 1024 the operand batches spilled)
+constexpr int LDL_WG_SUB = 256;                          // bottom subtrees: 4 wavefronts each
+constexpr int LDL_CS = DirectPlan::CELL_SLOTS;
+constexpr int LDL_ST = DirectPlan::CELL_STRIDE;
+constexpr int LDL_NW = DirectPlan::CELL_WAVES;
 
 // sum over the 7 lanes that share this lane's column index c (lanes 7c .. 7c+6)
 __device__ __forceinline__ double ldl_sum_over_r(double v, int c49) {
@@ -59,37 +75,29 @@ __device__ __forceinline__ double ldl_sum_over_c(double v, int r49) {
   return s;
 }
 
-__device__ __forceinline__ void ldl_phase_a(const LdlArgs& A, int s, int lane, int l49, int r, int c) {
-  const int j = A.lcol[s];
-  const bool diag = s == A.colptr[j];
-  double acc = 0.0;
-  for (int k = A.srcptr[s]; k < A.srcptr[s + 1]; ++k) acc += A.vals[(size_t)49 * A.src[k] + l49];
-  if (diag && r == c) acc += A.lambda;
-  double t = 0.0;
-  const int k1 = A.pairptr[s + 1];
-  for (int k = A.pairptr[s]; k < k1; ++k) {
-    const int sa = A.pa[k], sb = A.pb[k];
-    const double a = A.L[(size_t)49 * sa + l49];
-    const double bt = sa == sb ? a : A.L[(size_t)49 * sb + l49];
-#pragma unroll
-    for (int m = 0; m < 7; ++m) acc -= __shfl(a, 7 * m + r) * __shfl(bt, 7 * m + c);
-    if (diag) t += a * A.y[(size_t)7 * A.lcol[sa] + c];  // L(j,k)(r,c) y_k(c)
+// once per linearisation: Aperm[s] = sum of the H blocks behind block s of L; bp = permuted b
+__global__ __launch_bounds__(WG) void k_ldl_gather(LdlArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int nwv = gridDim.x * 4;
+  for (int s = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); s < A.nL; s += nwv) {
+    double acc = 0.0;
+    for (int k = A.srcptr[s]; k < A.srcptr[s + 1]; ++k) acc += A.vals[(size_t)49 * A.src[k] + l49];
+    if (lane < 49) A.Aperm[(size_t)49 * s + lane] = acc;
   }
-  if (lane < 49) A.L[(size_t)49 * s + lane] = acc;
-  if (diag) {
-    const double rs = ldl_sum_over_c(t, r);
-    if (lane < 7) A.y[(size_t)7 * j + lane] = A.b[(size_t)7 * A.perm[j] + lane] - rs;
-  }
+  for (int j = blockIdx.x * WG + threadIdx.x; j < 7 * A.nb; j += gridDim.x * WG)
+    A.bp[j] = A.b[(size_t)7 * A.perm[j / 7] + j % 7];
 }
 
-__device__ __forceinline__ void ldl_phase_b(const LdlArgs& A, int j, int lane, int l49, int r, int c,
-                                            double* w /*98 doubles of LDS, this wavefront's*/) {
-  const int s0 = A.colptr[j];
+// 7x7 Cholesky of the block in `acc` (lane = entry), its inverse, y_j; stores L(j,j), Dinv[j], y[j]
+__device__ __forceinline__ void ldl_factor_diag(const LdlArgs& A, int s, int j, double acc, double tacc,
+                                               double bpv, int lane, int l49, int r, int c,
+                                               double* w /*98 doubles of LDS, this wavefront's*/) {
   double* wi = w + 49;
-  if (lane < 49) w[lane] = A.L[(size_t)49 * s0 + lane];
+  if (lane < 49) w[lane] = acc;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {  // 7x7 Cholesky, lower triangle, entry (r, c) at r + 7c
+  if (lane == 0) {  // lower triangle, entry (r, c) at r + 7c
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -127,33 +135,40 @@ __device__ __forceinline__ void ldl_phase_b(const LdlArgs& A, int j, int lane, i
   __builtin_amdgcn_wave_barrier();
   const double lf = w[l49], li = wi[l49];
   if (lane < 49) {
-    A.L[(size_t)49 * s0 + lane] = lf;
+    A.L[(size_t)49 * s + lane] = lf;
     A.Dinv[(size_t)49 * j + lane] = li;
   }
-  // y_j = L(j,j)^-1 (b_j - sum_k L(j,k) y_k)
-  const double yr = ldl_sum_over_c(li * A.y[(size_t)7 * j + c], r);
+  // y_j = L(j,j)^-1 (b_j - sum_k L(j,k) y_k): the sum arrives as tacc (entry (r,c) = L(j,k)(r,c) y_k(c))
+  const double yraw = bpv - ldl_sum_over_c(tacc, r);    // depends on r only
+  const double yc = __shfl(yraw, c);                    // lane c holds row c
+  const double yr = ldl_sum_over_c(li * yc, r);
   if (lane < 7) A.y[(size_t)7 * j + lane] = yr;
   __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void ldl_phase_c(const LdlArgs& A, int s, int lane, int l49, int r, int c) {
-  const int j = A.lcol[s];
-  const double raw = A.L[(size_t)49 * s + l49];
-  const double li = A.Dinv[(size_t)49 * j + l49];
-  double xv = 0.0;
-#pragma unroll
-  for (int m = 0; m < 7; ++m) xv += __shfl(raw, 7 * m + r) * __shfl(li, 7 * m + c);  // raw L(j,j)^-T
-  if (lane < 49) A.L[(size_t)49 * s + lane] = xv;
 }
 
 // x_j = L(j,j)^-T (y_j - sum_{i > j} L(i,j)^T x_i)
 __device__ __forceinline__ void ldl_back(const LdlArgs& A, int j, int lane, int l49, int r, int c) {
   const int s0 = A.colptr[j], s1 = A.colptr[j + 1];
-  double t = 0.0;
-  for (int s = s0 + 1; s < s1; ++s)
-    t += A.L[(size_t)49 * s + l49] * A.xp[(size_t)7 * A.lrow[s] + r];
-  const double z = A.y[(size_t)7 * j + c] - ldl_sum_over_r(t, c);  // z(c), the same in lanes (., c)
+  const double yj = A.y[(size_t)7 * j + c];
   const double li = A.Dinv[(size_t)49 * j + l49];
+  double t = 0.0;
+  for (int sb = s0 + 1; sb < s1; sb += 64) {
+    const int vr = sb + lane < s1 ? A.lrow[sb + lane] : 0;  // rows of up to 64 blocks, one per lane
+    const int nn = s1 - sb < 64 ? s1 - sb : 64;
+    for (int q = 0; q < nn; q += 8) {  // eight blocks (and their x rows) in flight
+      double lv[8], xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < nn) {
+          lv[i] = A.L[(size_t)49 * (sb + q + i) + l49];
+          xv[i] = A.xp[(size_t)7 * __builtin_amdgcn_readlane(vr, q + i) + r];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < nn) t += lv[i] * xv[i];
+    }
+  }
+  const double z = yj - ldl_sum_over_r(t, c);  // z(c), the same in lanes (., c)
   const double p = __shfl(li, c + 7 * r) * z;  // Linv(c, r) z(c)
   const double xr = ldl_sum_over_c(p, r);
   if (lane < 7) {
@@ -164,7 +179,8 @@ __device__ __forceinline__ void ldl_back(const LdlArgs& A, int j, int lane, int 
 
 template <bool UP, bool DOWN>
 __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
-  __shared__ double lds[LDL_WG_TOP / 64][98];
+  __shared__ double lds_raw[LDL_NW][LDL_CS][49];  // a cell's blocks: Aperm rows, then raw blocks
+  __shared__ double lds_ch[LDL_NW][98];           // Cholesky scratch
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
@@ -172,19 +188,125 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
   const int r = l49 % 7, c = l49 / 7;
   const int g = g0 + blockIdx.x;
   const int lv0 = A.gptr[g], lv1 = A.gptr[g + 1];
+  const bool trace = A.dbg != nullptr && UP && DOWN && threadIdx.x == 0;
+  int ti = 0;
   if (UP) {
     for (int l = lv0; l < lv1; ++l) {
-      const int c0 = A.lcolp[l], c1 = A.lcolp[l + 1];
-      const int sb = A.colptr[c0], se = A.colptr[c1];
-      for (int s = sb + wave; s < se; s += nw) ldl_phase_a(A, s, lane, l49, r, c);
-      __syncthreads();
-      for (int j = c0 + wave; j < c1; j += nw) ldl_phase_b(A, j, lane, l49, r, c, lds[wave]);
-      __syncthreads();
-      for (int s = sb + wave; s < se; s += nw)
-        if (s != A.colptr[A.lcol[s]]) ldl_phase_c(A, s, lane, l49, r, c);
-      __syncthreads();
+      const int q0 = A.rptr[l], q1 = A.rptr[l + 1];
+      if (trace) A.dbg[ti++] = wall_clock64();
+      for (int q = q0; q < q1; ++q) {
+        const int32_t* cell = A.cells + (size_t)LDL_ST * q;
+        const int sa = cell[wave], sb = cell[wave + 1];
+        const int ka = cell[LDL_NW + 1 + wave], kb = cell[LDL_NW + 1 + wave + 1];
+        const int n = sb - sa;  // <= LDL_CS
+        // ---- index vectors of the cell and its Aperm rows: one round trip ----
+        const int li_ = lane < n ? lane : (n > 0 ? n - 1 : 0);
+        int vpp = 0, vlc = 0, vlr = 0;
+        if (n > 0) {
+          vpp = A.pairptr[sa + (lane <= n ? lane : n)];
+          vlc = A.lcol[sa + li_];
+          vlr = A.lrow[sa + li_];
+        }
+        int kbase = ka;
+        int ia = 0, ib = 0, ic = 0;
+        if (kbase + lane < kb) { ia = A.pa[kbase + lane]; ib = A.pb[kbase + lane]; ic = A.pcol[kbase + lane]; }
+        {
+          double tmp[LDL_CS];
+#pragma unroll
+          for (int t = 0; t < LDL_CS; ++t)
+            if (t < n) tmp[t] = A.Aperm[(size_t)49 * (sa + t) + l49];
+#pragma unroll
+          for (int t = 0; t < LDL_CS; ++t)
+            if (t < n && lane < 49) lds_raw[wave][t][lane] = tmp[t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase A + B: the cell's products as one stream, eight operands pairs at a time ----
+        int t = 0, k = ka, kend = 0, jt = 0;
+        bool diag = false;
+        double acc = 0.0, tacc = 0.0, bpv = 0.0;
+        auto begin_slot = [&]() {
+          jt = __builtin_amdgcn_readlane(vlc, t);
+          diag = __builtin_amdgcn_readlane(vlr, t) == jt;
+          kend = __builtin_amdgcn_readlane(vpp, t + 1);
+          acc = lds_raw[wave][t][l49];
+          if (diag && r == c) acc += A.lambda;
+          tacc = 0.0;
+          bpv = diag ? A.bp[(size_t)7 * jt + r] : 0.0;
+        };
+        auto end_slot = [&]() {
+          if (diag) ldl_factor_diag(A, sa + t, jt, acc, tacc, bpv, lane, l49, r, c, lds_ch[wave]);
+          else if (lane < 49) lds_raw[wave][t][lane] = acc;  // waits for L(j,j)^-1 (phase C)
+        };
+        if (n > 0) begin_slot();
+        while (t < n) {
+          if (k == kend) {  // this block has all its products
+            end_slot();
+            ++t;
+            if (t < n) begin_slot();
+            continue;
+          }
+          if (k - kbase >= 64) {  // next 64 product indices
+            kbase = k;
+            ia = ib = ic = 0;
+            if (kbase + lane < kb) { ia = A.pa[kbase + lane]; ib = A.pb[kbase + lane]; ic = A.pcol[kbase + lane]; }
+          }
+          const int off = k - kbase;
+          int m = kb - k < 8 ? kb - k : 8;
+          if (64 - off < m) m = 64 - off;
+          double av[8], bv[8], yv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < m) {
+              const int s_a = __builtin_amdgcn_readlane(ia, off + i);
+              const int s_b = __builtin_amdgcn_readlane(ib, off + i);
+              av[i] = A.L[(size_t)49 * s_a + l49];
+              bv[i] = A.L[(size_t)49 * s_b + l49];
+              yv[i] = A.y[(size_t)7 * __builtin_amdgcn_readlane(ic, off + i) + c];
+            }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < m) {
+              while (k + i == kend) {  // (a block boundary inside the batch)
+                end_slot();
+                ++t;
+                begin_slot();  // t < n: product k + i belongs to a block of this cell
+              }
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) acc -= __shfl(av[i], 7 * mm + r) * __shfl(bv[i], 7 * mm + c);
+              tacc += av[i] * yv[i];  // (used by diagonal blocks only)
+            }
+          k += m;
+        }
+        __syncthreads();
+        if (trace) A.dbg[ti++] = wall_clock64();
+        // ---- phase C: off-diagonal blocks of the cell times L(j,j)^-T ----
+        {
+          double dv[LDL_CS];
+#pragma unroll
+          for (int tt = 0; tt < LDL_CS; ++tt)
+            if (tt < n) {
+              const int jj = __builtin_amdgcn_readlane(vlc, tt);
+              dv[tt] = A.Dinv[(size_t)49 * jj + l49];
+            }
+#pragma unroll
+          for (int tt = 0; tt < LDL_CS; ++tt)
+            if (tt < n) {
+              const int jj = __builtin_amdgcn_readlane(vlc, tt);
+              if (__builtin_amdgcn_readlane(vlr, tt) != jj) {
+                const double raw = lds_raw[wave][tt][l49];
+                double xv = 0.0;
+#pragma unroll
+                for (int mm = 0; mm < 7; ++mm) xv += __shfl(raw, 7 * mm + r) * __shfl(dv[tt], 7 * mm + c);
+                if (lane < 49) A.L[(size_t)49 * (sa + tt) + lane] = xv;
+              }
+            }
+        }
+        __syncthreads();
+      }
     }
   }
+  if (trace) A.dbg[ti++] = wall_clock64();
   if (DOWN) {
     for (int l = lv1 - 1; l >= lv0; --l) {
       const int c0 = A.lcolp[l], c1 = A.lcolp[l + 1];
@@ -192,4 +314,5 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
       __syncthreads();
     }
   }
+  if (trace) { A.dbg[ti++] = wall_clock64(); A.dbg[255] = ti; }
 }

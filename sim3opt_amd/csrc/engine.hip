@@ -1041,6 +1041,8 @@ class Engine {
   // (piecewise-constant prolongation under-estimates the correction; Stueben / Blaheta)
   double amg_over_l[AMG_MAX_LEVELS + 1];
   double amg_over = 1.0;               // (the factor of the launch being issued)
+  int amg_pivot = 14;                  // pivot block of the dense coarsest inverse (14 or 28 rows: the same
+                                       // total time -- the in-wavefront pivot inverse is what costs)
   int amg_status = 0;                  // first collective error inside a cycle
   std::string amg_err;
   // exact sparse block Cholesky (direct.hpp, direct_kernels.hpp): LinearSolverEigen's role on
@@ -1351,6 +1353,7 @@ class Engine {
     }
     if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("SIM3OPT_AMG_FP32")) amg_fp32 = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("SIM3OPT_AMG_PIVOT")) amg_pivot = std::atoi(ev) >= 28 ? 28 : 14;
     // measured on config 3: 1.8 into level 0 and 1.6 below cut the PCG iterations of
     // a solve from 56 to 43 (cycle 1/3) and from 29 to 25 (cycle 2/3); 2.0 (the limit for an exact
     // coarse solve) is no better
@@ -1460,7 +1463,7 @@ class Engine {
       const int gg = (int)((Cc.nnzb + 3) / 4), gw = (Cc.nb + 3) / 4;
       if (l == 0) {
         hipLaunchKernelGGL((k_amg_galerkin<true>), dim3(gg), dim3(WG), 0, stream, (int)Cc.nnzb, F.gptr,
-                           F.gblk, F.grow, F.colidx, F.vals, d_P, Cc.vals);
+                           F.gblk, F.grow, F.colidx, F.vals, d_P, Cc.vals, amg_fp32 ? F.vals32 : (float*)nullptr);
         if (comm.active()) {
           // a rank holds the blocks of its own rows (the others are zero): the products above are
           // partial sums; summed over the ranks, level 1 and everything below is replicated
@@ -1471,15 +1474,16 @@ class Engine {
                            d_P, Cc.W);
       } else {
         hipLaunchKernelGGL((k_amg_galerkin<false>), dim3(gg), dim3(WG), 0, stream, (int)Cc.nnzb, F.gptr,
-                           F.gblk, F.grow, F.colidx, F.vals, (const double*)nullptr, Cc.vals);
+                           F.gblk, F.grow, F.colidx, F.vals, (const double*)nullptr, Cc.vals,
+                           amg_fp32 ? F.vals32 : (float*)nullptr);
         hipLaunchKernelGGL((k_amg_wsum<false>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem,
                            F.W, Cc.W);
       }
       hipLaunchKernelGGL(k_amg_copydiag, dim3(grid_for(49 * (int64_t)Cc.nb, WG)), dim3(WG), 0, stream,
                          Cc.nb, Cc.rowptr, Cc.vals, Cc.diagH);
     }
-    if (amg_fp32)
-      for (int l = 0; l < nl; ++l) {
+    if (amg_fp32)  // (the Galerkin products wrote the FP32 copies of the levels they read)
+      for (int l = nl - 1; l < nl; ++l) {
         const size_t cnt = (size_t)49 * (size_t)amg[l].nnzb;
         hipLaunchKernelGGL(k_to_f32, dim3(grid_for((int64_t)(cnt / 4), WG)), dim3(WG), 0, stream, cnt,
                            (const double*)amg[l].vals, amg[l].vals32);
@@ -1505,21 +1509,29 @@ class Engine {
     (void)hipMemsetAsync(d_Ainv2, 0, sizeof(double) * (size_t)nd * nd, stream);
     hipLaunchKernelGGL(k_amg_dense_fill, dim3(grid_for(49 * Lc.nnzb, WG)), dim3(WG), 0, stream, Lc.nb,
                        Lc.rowptr, Lc.colidx, Lc.vals, d_Ainv2);
-    const int nsteps = (Lc.nb + 1) / 2;  // 14-row pivot blocks, a last one of 7 rows when nb is odd
+    // pivot blocks of `amg_pivot` rows (14: 82 launches of 23 us for 1141 unknowns; 28: 41 of 47 us), then
+    // 14, then 7 for the tail; an even number of steps would end in d_Ainv2: start from d_Ainv then
+    int nsteps = 0;
+    for (int k0 = 0; k0 < nd;) { k0 += nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7); ++nsteps; }
     double *src = d_Ainv2, *dst = d_Ainv;
-    if (nsteps % 2 == 0) {  // an even number of steps would end in d_Ainv2: start from d_Ainv instead
+    if (nsteps % 2 == 0) {
       (void)hipMemcpyAsync(d_Ainv, d_Ainv2, sizeof(double) * (size_t)nd * nd, hipMemcpyDeviceToDevice, stream);
       src = d_Ainv;
       dst = d_Ainv2;
     }
     const dim3 gt((nd + 63) / 64, (nd + 63) / 64);
-    for (int k0 = 0; k0 < nd; k0 += 14) {
-      if (nd - k0 >= 14)
+    for (int k0 = 0; k0 < nd;) {
+      const int pb = nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7);
+      if (pb == 28)
+        hipLaunchKernelGGL((k_amg_dense_gj_step<28>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
+                           dst, d_sc);
+      else if (pb == 14)
         hipLaunchKernelGGL((k_amg_dense_gj_step<14>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
                            dst, d_sc);
       else
         hipLaunchKernelGGL((k_amg_dense_gj_step<7>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
                            dst, d_sc);
+      k0 += pb;
       std::swap(src, dst);
     }  // the inverse is in d_Ainv
   }
@@ -1681,10 +1693,11 @@ class Engine {
     int32_t subtree = 0;
     if (const char* ev = std::getenv("SIM3OPT_DIRECT_MAX_PAIRS")) max_pairs = std::atoll(ev);  // tuning knobs
     if (const char* ev = std::getenv("SIM3OPT_DIRECT_SUBTREE")) subtree = std::atoi(ev);
-    if (const char* ev = std::getenv("SIM3OPT_DIRECT_WG_SUB")) ldl_wg_sub = std::max(64, std::min(1024, std::atoi(ev) / 64 * 64));
+    if (const char* ev = std::getenv("SIM3OPT_DIRECT_WG_SUB")) ldl_wg_sub = std::max(64, std::min(LDL_WG_TOP, std::atoi(ev) / 64 * 64));
     if (!forced && nb > 60000) return SIM3OPT_OK;
     std::string why;
-    if (!build_direct_plan(nb, s.rowptr.data(), s.colidx.data(), max_pairs, subtree, dplan, why)) {
+    if (!build_direct_plan(nb, s.rowptr.data(), s.colidx.data(), max_pairs, subtree, dplan, why,
+                           ldl_wg_sub / 64)) {
       dplan = DirectPlan();
       if (forced) {
         err = "linear_solver = 1: " + why;
@@ -1704,13 +1717,27 @@ class Engine {
     DCHK(direct_up(ldl.pairptr, dplan.pairptr, err));
     DCHK(direct_up(ldl.pa, dplan.pa, err));
     DCHK(direct_up(ldl.pb, dplan.pb, err));
+    DCHK(direct_up(ldl.pcol, dplan.pcol, err));
     DCHK(direct_up(ldl.gptr, dplan.gptr, err));
     DCHK(direct_up(ldl.lcolp, dplan.lcolp, err));
+    DCHK(direct_up(ldl.rptr, dplan.rptr, err));
+    DCHK(direct_up(ldl.cells, dplan.cells, err));
+    ldl.nb = nb;
+    ldl.nL = (int32_t)dplan.nL;
+    DCHK(direct_alloc(ldl.Aperm, (size_t)49 * dplan.nL, err));
+    DCHK(direct_alloc(ldl.bp, (size_t)7 * nb, err));
     DCHK(direct_alloc(ldl.L, (size_t)49 * dplan.nL, err));
     DCHK(direct_alloc(ldl.Dinv, (size_t)49 * nb, err));
     DCHK(direct_alloc(ldl.y, (size_t)7 * nb, err));
     DCHK(direct_alloc(ldl.xp, (size_t)7 * nb, err));
 #undef DCHK
+    ldl.dbg = nullptr;
+    if (std::getenv("SIM3OPT_DIRECT_TRACE")) {  // tuning aid: per-level time stamps of the top group
+      double* p = nullptr;
+      int rc2 = direct_alloc(p, 256, err);
+      if (rc2) return rc2;
+      ldl.dbg = reinterpret_cast<long long*>(p);
+    }
     if (opt.verbose)
       std::fprintf(stderr,
                    "sim3opt: exact block Cholesky: %d columns, %lld blocks in L, %lld block products, "
@@ -1736,6 +1763,14 @@ class Engine {
     if (ng > 1)
       hipLaunchKernelGGL((k_ldl<false, true>), dim3(ng - 1), dim3(ldl_wg_sub), 0, stream, ldl, 0);
     HIPCHK(hipGetLastError());
+    if (ldl.dbg) {
+      long long h[256];
+      HIPCHK(hipStreamSynchronize(stream));
+      HIPCHK(hipMemcpy(h, ldl.dbg, sizeof(h), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "sim3opt: direct solve, top group stamps [us from start] (level start / after A+B per round / ... / down start / end):");
+      for (long long i = 0; i < h[255] && i < 255; ++i) std::fprintf(stderr, " %.1f", (h[i] - h[0]) * 0.01);
+      std::fprintf(stderr, "\n");
+    }
     return SIM3OPT_OK;
   }
 
@@ -1779,6 +1814,13 @@ class Engine {
     if (comm.active()) {  // non-negative doubles order like their bit patterns
       int rc = comm.allreduce(reinterpret_cast<double*>(&d_sc->maxdiag_bits), 1, 1, stream, err);
       if (rc) return rc;
+    }
+    if (use_direct) {  // the factorisation's starting blocks: H in the layout of L, b permuted
+      ldl.vals = d_vals;
+      ldl.b = d_b;
+      hipLaunchKernelGGL(k_ldl_gather, dim3(std::max(1, std::min(1024, (ldl.nL + 3) / 4))), dim3(WG), 0,
+                         stream, ldl);
+      HIPCHK(hipGetLastError());
     }
     linearized = true;
     amg_stale = true;

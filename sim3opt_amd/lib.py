@@ -109,7 +109,7 @@ SYMBOLS = {
     "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
     "sim3opt_linear_solver_in_use": (C.c_int, [_vp]),
     "sim3opt_direct_plan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), _ip, _ip, _ip, _ip, _ip, _ip,
-                                      _ip, _ip, _ip, _ip]),
+                                      _ip, _ip, _ip, _ip, _ip, _ip]),
     "sim3opt_comm_allgather_plan": (C.c_int, [C.c_int32, C.c_int32, _ip, C.POINTER(C.c_int64),
                                               C.POINTER(C.c_int64)]),
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
@@ -423,16 +423,18 @@ class Graph:
         """Plan of the exact sparse block Cholesky as a dict of numpy arrays; host only."""
         dims = np.zeros(8, dtype=np.int64)
         dp = dims.ctypes.data_as(C.POINTER(C.c_int64))
-        null = [None] * 10
+        null = [None] * 12
         self._chk(self._L.sim3opt_direct_plan(self._g, int(max_pairs), dp, *null))
-        nb, nL, npairs, height, ngroups, nlev, nsrc = (int(x) for x in dims[:7])
+        nb, nL, npairs, height, ngroups, nlev, nsrc, nrounds = (int(x) for x in dims[:8])
         arr = dict(perm=nb, colptr=nb + 1, lrow=nL, srcptr=nL + 1, src=nsrc, pairptr=nL + 1,
-                   pa=npairs, pb=npairs, gptr=ngroups + 1, lcolp=nlev + 1)
+                   pa=npairs, pb=npairs, gptr=ngroups + 1, lcolp=nlev + 1, rptr=nlev + 1,
+                   cells=18 * nrounds)
         out = {k: np.zeros(max(n, 1), dtype=np.int32) for k, n in arr.items()}
         self._chk(self._L.sim3opt_direct_plan(self._g, int(max_pairs), dp,
                                               *[_p(out[k], _ip) for k in arr]))
         out = {k: out[k][:n] for k, n in arr.items()}
-        out.update(nb=nb, nL=nL, npairs=npairs, height=height, ngroups=ngroups, nlevels=nlev)
+        out.update(nb=nb, nL=nL, npairs=npairs, height=height, ngroups=ngroups, nlevels=nlev,
+                   nrounds=nrounds)
         return out
 
     def amg_hierarchy(self):

@@ -112,6 +112,21 @@ def test_plan_solves_like_dense(name):
     for j in range(nb):  # diagonal first, rows ascending
         r = P["lrow"][P["colptr"][j]:P["colptr"][j + 1]]
         assert r[0] == j and (np.diff(r) > 0).all()
+    # the kernel's work split: the rounds of a level tile its blocks exactly once, in order, in cells
+    # of at most 8 blocks, and every cell knows its product range
+    assert len(P["rptr"]) == P["nlevels"] + 1 and P["rptr"][-1] == P["nrounds"]
+    for g in range(P["ngroups"]):
+        nw = 8 if g == P["ngroups"] - 1 else 4
+        for l in range(P["gptr"][g], P["gptr"][g + 1]):
+            S0, S1 = P["colptr"][P["lcolp"][l]], P["colptr"][P["lcolp"][l + 1]]
+            nxt = S0
+            for q in range(P["rptr"][l], P["rptr"][l + 1]):
+                cell = P["cells"][18 * q:18 * q + 18]
+                assert cell[0] == nxt and (np.diff(cell[:9]) >= 0).all() and (np.diff(cell[:nw + 1]) <= 8).all()
+                assert (cell[nw:9] == cell[nw]).all()  # wavefronts beyond the group's own stay idle
+                assert (cell[9:] == P["pairptr"][cell[:9]]).all()
+                nxt = cell[nw]
+            assert nxt == S1 and P["rptr"][l + 1] > P["rptr"][l]
     vals, M = random_spd_on_pattern(rowptr, colidx, 11)
     b = np.random.default_rng(12).standard_normal((nb, 7))
     lam = 0.5
