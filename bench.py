@@ -321,6 +321,11 @@ def main():
                                    f"rel tol {args.pcg_rel_tol:g}",
                        "vertices": args.vertices, "edges": args.edges,
                        "fix_small_angle_b": args.fix_small_angle_b,
+                       "arithmetic": ("exact small-angle B coefficient -- NOT the reference's as-written "
+                                      "sim3_rv.h:166/:290 (with it LM stalls on this graph: see "
+                                      "reference_arithmetic; the reference's own arithmetic is run where the "
+                                      "reference runs it: kitti00_reference_configuration)")
+                                     if args.fix_small_angle_b else "reference (B as written)",
                        "preconditioner": prec_name,
                        "parallelism": "single GPU" if world == 1 else f"row-partition x{world}",
                        "transport": transport_used},
