@@ -292,11 +292,11 @@ def main():
         # (the PCG's SpMV also reads r once for the fused r.z reduction)
         spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 3 * 7 * rows_local * 8
         # HBM bytes per SpMV launch from the last rocprofv3 --pmc collection (separate passes;
-        # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r1_pmc_spmv.json
+        # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r2_pmc_spmv.json
         traffic = None
         try:
             if world == 1 and args.vertices == 100000 and args.edges == 1000000:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_spmv.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_spmv.json")))
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         except Exception:
             traffic = None
