@@ -99,6 +99,41 @@ def test_linear_solver_option():
     assert synth.rmse(Gd.get_vertices(), Gi.get_vertices()) < 1e-6
 
 
+def test_direct_lm_with_information_huber_parallel_edges_and_two_fixed_vertices():
+    """The exact solver under everything the edge / vertex surface offers at once: non-identity
+    information matrices, a Huber kernel, duplicated (parallel) edges, two fixed vertices (one in the
+    middle of the chain), arbitrary vertex ids -- LM against the oracle in the well-posed arithmetic."""
+    synth.DRIFT_TARGET = 0.05
+    g = synth.chain_loop(300, 340)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(g["v0"].shape[0], 25, replace=False)  # parallel edges
+    v0 = np.concatenate([g["v0"], g["v0"][dup]]).astype(np.int32)
+    v1 = np.concatenate([g["v1"], g["v1"][dup]]).astype(np.int32)
+    meas = np.concatenate([g["meas"], g["meas"][dup]])
+    fixed = g["fixed"].copy()
+    fixed[150] = 1
+    M = rng.standard_normal((v0.shape[0], 7, 7)) * 0.3
+    info = np.einsum("kij,klj->kil", M, M) + np.eye(7)
+    ids = (np.arange(300) * 7 + 3).astype(np.int32)
+    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6)
+    G.add_vertices(g["states"], fixed, ids)
+    G.add_edges(ids[v0], ids[v1], meas, info=info, kernel=L.KERNEL_HUBER, kernel_delta=0.3)
+    G.initialize()
+    assert G.linear_solver_in_use() == 1
+    OG = O.Graph(g["states"], fixed, v0, v1, meas, info=info.transpose(0, 2, 1).reshape(-1, 49),
+                 kernel=1, kdelta=0.3)
+    o = O.default_options(fix_small_angle_b=1, fd_delta=1e-6)
+    n = G.optimize(8)
+    it, tr = OG.optimize(8, o)
+    st = G.stats()
+    assert n == it == 8
+    assert [s.trials for s in st] == [t.trials for t in tr]
+    for k in range(8):
+        assert abs(st[k].chi2_after - tr[k].chi2_after) < 1e-7 * tr[k].chi2_after, k
+    assert synth.rmse(G.get_vertices(), OG.states) < 1e-6
+    assert np.array_equal(G.get_vertices()[150], g["states"][150])  # the fixed vertex did not move
+
+
 # ------------------------------------------------------------------ KITTI-00, reference configuration
 @pytest.mark.parametrize("name,one", [("one_loop", True), ("all_loops", False)])
 def test_kitti_lockstep_with_oracle(name, one):
