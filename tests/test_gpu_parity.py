@@ -618,6 +618,25 @@ def test_config3_manhattan_full_size_properties():
     assert synth.rmse(G.get_vertices(), g["gt"]) < synth.rmse(g["states"], g["gt"])
 
 
+def test_overcorrected_cycle_falls_back_instead_of_failing_the_trial(monkeypatch):
+    """The multigrid cycle scales its coarse corrections by 1.8 / 1.6, which is safe
+    only while the inexact coarse solves stay within (0, 2) of the exact ones.  Forced beyond that
+    (1.9 / 1.7 breaks the PCG down on this graph) the solver must notice and solve again with the
+    plain cycle -- not report a failed solve, which would make LM reject a good trial."""
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan()
+    ref = mk(g, fix_small_angle_b=1, pcg_rel_tol=1e-8)
+    assert ref.optimize(3) == 3
+    monkeypatch.setenv("SIM3OPT_AMG_OVER", "1.9,1.7")
+    G = mk(g, fix_small_angle_b=1, pcg_rel_tol=1e-8)
+    assert G.optimize(3) == 3
+    st, sr = G.stats(), ref.stats()
+    assert [s.trials for s in st] == [s.trials for s in sr] == [1, 1, 1]
+    for a, b in zip(st, sr):
+        assert abs(a.chi2_after - b.chi2_after) < 1e-5 * b.chi2_after
+        assert a.pcg_rel_res <= 1e-8
+
+
 # ------------------------------------------------------------------ edge cases
 def test_minimal_and_degenerate_graphs():
     I8 = np.array([0, 0, 0, 1, 0, 0, 0, 1.0])
