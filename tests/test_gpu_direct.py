@@ -226,3 +226,38 @@ def test_kitti_all_loops_reference_run():
     assert abs(st[-1].chi2_after - tr[-1].chi2_after) < 1e-2 * tr[-1].chi2_after
     rm = synth.rmse(G.get_vertices(), OG.states)
     assert rm < 1e-2, rm
+
+
+@pytest.mark.parametrize("one,rmse_max,chi_rel", [(True, 1e-4, 1e-6), (False, 5e-2, 1e-3)])
+def test_kitti_stepwise_reference_run(one, rmse_max, chi_rel):
+    """BASELINE.json configs[4] in the reference's meaning (kitti_surf.cpp:887-1047): scales from the
+    null vector, scale + translation LM with frozen rotations (100 it), Sim(3) LM warm-started from it
+    (100 it), default options (delta = 1e-9, B as written), through the exact Cholesky.  Measured
+    against the oracle from the same scale initialisation: RMSE 3.9e-5 m (one loop) / 0.02 m (118
+    loops), final chi2 to 2e-8 / 5e-5; against KITTI ground truth both land at 13.4 m with all loops
+    (the direct run: 117 m) -- the staging is what makes the reference's result usable."""
+    g = K.build_direct_graph(one)
+    G = L.Graph()
+    G.add_vertices(g["states"], g["fixed"])
+    G.add_edges(g["v0"], g["v1"], g["meas"])
+    G.stepwise_scale_init()
+    st0 = G.get_vertices().copy()
+    G.set_options(dof_mask=0x78)
+    G.initialize()
+    assert G.linear_solver_in_use() == 1
+    q0 = G.get_vertices()[:, :4].copy()
+    assert G.optimize(100) > 0
+    assert np.array_equal(G.get_vertices()[:, :4], q0)  # rotations frozen
+    chi_st = G.stats()[-1].chi2_after
+    G.set_options(dof_mask=127)
+    assert G.optimize(100) > 0
+    OG = O.Graph(st0, g["fixed"], g["v0"], g["v1"], g["meas"])
+    i2, tr2 = OG.optimize(100, O.default_options(dof_mask=0x78))
+    i3, tr3 = OG.optimize(100)
+    assert abs(chi_st - tr2[-1].chi2_after) < chi_rel * tr2[-1].chi2_after
+    assert abs(G.stats()[-1].chi2_after - tr3[-1].chi2_after) < chi_rel * tr3[-1].chi2_after
+    rm = synth.rmse(G.get_vertices(), OG.states)
+    assert rm < rmse_max, rm
+    if not one:
+        gt = np.loadtxt(os.path.join(K.FIXTURE, "gt_kf.txt"), comments="%")[:, [4, 8, 12]]
+        assert L.align_trajectory(synth.positions(G.get_vertices()), gt)[1] < 20.0
