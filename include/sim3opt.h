@@ -120,7 +120,7 @@ void sim3opt_options_default(sim3opt_options* o);
 /* g2o::SparseOptimizer ctor + setAlgorithm                         kitti_surf.cpp:552-558 */
 sim3opt_graph* sim3opt_create(void);
 void sim3opt_destroy(sim3opt_graph* g);
-/* May be called at any time.  device, preconditioner and chain_segment are read by
+/* May be called at any time.  device, linear_solver, preconditioner and chain_segment are read by
  * sim3opt_initialize; every other field takes effect at the next call that uses it. */
 int sim3opt_set_options(sim3opt_graph* g, const sim3opt_options* o);
 int sim3opt_get_options(const sim3opt_graph* g, sim3opt_options* o);
