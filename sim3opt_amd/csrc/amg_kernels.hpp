@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (u < m) {
-        if (vals32_f && lane < 49) vals32_f[(size_t)49 * kk[u] + lane] = (float)av[u];
+        if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
         if (HASP) {
           double t = 0.0;  // T = A P_j
 #pragma unroll

@@ -168,6 +168,13 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho, doub
   }
 }
 
+// FP32 copies of the blocks (multigrid matrix passes) are stored as interleaved PAIRS: entry e of
+// block k sits at 98 (k / 2) + 2 e + (k mod 2), so that ONE 8-byte load per lane brings the same entry
+// of two consecutive blocks -- 392 bytes per wavefront instruction, like an FP64 block, instead of 196.
+__host__ __device__ __forceinline__ size_t f32_pair_index(int64_t k, int e) {
+  return (size_t)98 * (size_t)(k >> 1) + (size_t)(2 * e) + (size_t)(k & 1);
+}
+
 struct EdgeArgs {
   int32_t e_lo, e_hi;  // edge range evaluated by this launch (rank's share in multi-GPU chi2)
   const int32_t* ev0;
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
   if (row >= r1) return;
   double a[7][7];
   double* blk = vals + (size_t)49 * rowptr[row];
-  float* blk32 = vals32 ? vals32 + (size_t)49 * rowptr[row] : nullptr;
+  const int64_t kd = rowptr[row];  // the row's diagonal block
   const double* src = diagH ? diagH + (size_t)49 * row : blk;
 #pragma unroll
   for (int c = 0; c < 7; ++c)
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
       for (int r = 0; r < 7; ++r) {
         a[r][c] += lambda * w[7 * c + r];
         blk[7 * c + r] = a[r][c];
-        if (blk32) blk32[7 * c + r] = (float)a[r][c];
+        if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
       }
   } else {
 #pragma unroll
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 __global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restrict__ src,
                                                float* __restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    dst[i] = (float)src[i];
+    dst[f32_pair_index((int64_t)(i / 49), (int)(i % 49))] = (float)src[i];
 }
 
 #include "amg_kernels.hpp"
@@ -573,28 +580,48 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
     int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
     int row = rA;
     int k1 = __builtin_amdgcn_readlane(rpv, 0);
-    // column indices, 64 blocks at a time, one per lane; window w covers [kbeg + 64 w, +64)
-    int cbase = kbeg;
+    // FP32 blocks come in interleaved pairs (f32_pair_index): chunks start at an even block index,
+    // a leading block of the previous span is loaded and skipped
+    constexpr bool PAIR = sizeof(VT) == 4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int k0 = PAIR ? (kbeg & ~1) : kbeg;
+    const int pmax = (kend - 1) >> 1;
+    auto load_chunk = [&](int ks, VT* dst) {
+      if (PAIR) {
+#pragma unroll
+        for (int u = 0; u < CH; u += 2) {
+          const int pp = (ks + u) >> 1;
+          const f32x2* vp = reinterpret_cast<const f32x2*>(vals) + (size_t)49 * (pp < pmax ? pp : pmax) + l49;
+          const f32x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
+          dst[u] = (VT)t.x;
+          dst[u + 1] = (VT)t.y;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int kk = ks + u < kend ? ks + u : kend - 1;
+          const VT* vp = vals + (size_t)49 * kk + l49;
+          dst[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
+        }
+      }
+    };
+    // column indices, 64 blocks at a time, one per lane; window w covers [k0 + 64 w, +64)
+    int cbase = k0;
     int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
     int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
     double acc = 0.0;
     VT vc[CH], vn[CH];
     double xgc, xgn = 0.0;
-    // prologue: chunk at kbeg
+    // prologue: chunk at k0
     {
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int kk = kbeg + u < kend ? kbeg + u : kend - 1;
-        const VT* vp = vals + (size_t)49 * kk + l49;
-        vc[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
-      }
-      const int kk = kbeg + gu < kend ? kbeg + gu : kend - 1;
+      load_chunk(k0, vc);
+      const int kk = k0 + gu < kend ? k0 + gu : kend - 1;
       const int colu = __shfl(cv, kk - cbase);
       xgc = p[(size_t)7 * colu + gc];
       if (MODE == 3) xgc += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
     }
-    row_begin(row, 0, xgc);
-    for (int k = kbeg; k < kend; k += CH) {
+    row_begin(row, kbeg - k0, xgc);
+    for (int k = k0; k < kend; k += CH) {
       const int kn = k + CH;
       if (kn < kend) {  // issue the next chunk before consuming this one
         if (kn - cbase >= 64) {  // next chunk starts a new 64-block window (CH divides 64)
@@ -602,12 +629,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
           cv = cvn;
           cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
         }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int kk = kn + u < kend ? kn + u : kend - 1;
-          const VT* vp = vals + (size_t)49 * kk + l49;
-          vn[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
-        }
+        load_chunk(kn, vn);
         const int kk = kn + gu < kend ? kn + gu : kend - 1;
         const int colu = __shfl(cv, kk - cbase);
         xgn = p[(size_t)7 * colu + gc];
@@ -616,7 +638,7 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int kk = k + u;
-        if (kk < kend) {
+        if (kk >= kbeg && kk < kend) {
           if (kk == k1) {  // row `row` is complete
             row_end(row, acc);
             acc = 0.0;
@@ -1445,7 +1467,9 @@ class Engine {
         AMGCHK(amg_alloc(L.t, (size_t)7 * L.nb, err));
       }
       if (amg_fp32) {
-        HIPCHK(hipMalloc((void**)&L.vals32, sizeof(float) * 49 * (size_t)std::max<int64_t>(L.nnzb, 1)));
+        const size_t n32 = (size_t)98 * (size_t)((std::max<int64_t>(L.nnzb, 1) + 1) / 2);  // whole pairs
+        HIPCHK(hipMalloc((void**)&L.vals32, sizeof(float) * n32));
+        HIPCHK(hipMemset(L.vals32, 0, sizeof(float) * n32));
         amg_owned.push_back(L.vals32);
       }
       if (l + 1 < nl) {
