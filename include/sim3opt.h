@@ -303,6 +303,54 @@ int sim3opt_write_bal(const char* path, int32_t n_cams, const double* Rw2c, cons
  * identity information, for re-running it in stock g2o */
 int sim3opt_write_g2o(sim3opt_graph* g, const char* path);
 
+/* ---- bundle adjustment hand-off: the reference's ba_demo on the GPU ----
+ * bal_example.cpp:44-243: g2o::VertexSE3Expmap cameras (T_w2c), g2o::VertexSBAPointXYZ points
+ * (marginalised), g2o::EdgeProjectXYZ2UV with ONE fixed g2o::CameraParameters(f, pp, 0) (:90-97),
+ * information I / pixel_noise^2 (:147), g2o::RobustKernelHuber(2.5) (:149-153), Levenberg-Marquardt
+ * over BlockSolver_6_3 + LinearSolverEigen (:76-88), optimize(maxIterations) (:213).  No vertex is
+ * fixed (the reference fixes none); the damping carries the gauge, as it does there.
+ * Device pipeline: sim3opt_amd/csrc/ba.hip.  No CPU fallback: SIM3OPT_ERR_NO_DEVICE without a GPU. */
+typedef struct sim3opt_ba sim3opt_ba;
+
+typedef struct sim3opt_ba_options {
+  double huber_delta;       /* RobustKernelHuber delta; 0 = no robust kernel      default 2.5  :151 */
+  double pixel_noise;       /* information = I / pixel_noise^2                     default 1.0  :62  */
+  double tau;               /* lambda_0 = tau * max diag(H)                        default 1e-5      */
+  double user_lambda_init;  /* > 0: used instead                                   default 0         */
+  int32_t max_trials;       /* LM trials per iteration                             default 10        */
+  int32_t pcg_max_iters;    /* reduced camera system; 0 = automatic                default 0         */
+  double pcg_rel_tol;       /* |r|_M / |r0|_M of the reduced system                default 1e-12     */
+  int32_t device;           /* HIP device ordinal, -1 = current                    default -1        */
+  int32_t verbose;          /* one line per LM iteration on stderr                 default 0    :72  */
+} sim3opt_ba_options;
+
+void sim3opt_ba_options_default(sim3opt_ba_options* o);
+sim3opt_ba* sim3opt_ba_create(void);
+void sim3opt_ba_destroy(sim3opt_ba* b);
+const char* sim3opt_ba_last_error(const sim3opt_ba* b);
+int sim3opt_ba_set_options(sim3opt_ba* b, const sim3opt_ba_options* o);
+/* cameras: n_cams x 7 [qx qy qz qw tx ty tz] of T_w2c (the SE3Quat of :170-172); points n x 3;
+ * observations (camera index, point index, u, v) as the BAL rows (:134-158).  Indices out of range
+ * -> SIM3OPT_ERR_ARG (the reference asserts).  focal / cx / cy: the fixed CameraParameters. */
+int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, int32_t n_points,
+                           const double* points, int32_t n_obs, const int32_t* obs_cam,
+                           const int32_t* obs_point, const double* obs_uv, double focal, double cx,
+                           double cy);
+/* the BAL file ba_demo takes as argv[1] (:104-189; per-camera f, k1, k2 are read and ignored as
+ * there: the projection uses the fixed focal / cx / cy) */
+int sim3opt_ba_read_bal(sim3opt_ba* b, const char* path, double focal, double cx, double cy);
+int sim3opt_ba_dims(const sim3opt_ba* b, int32_t* n_cams, int32_t* n_points, int32_t* n_obs);
+/* robustified chi2 of the current estimates (SparseOptimizer::activeRobustChi2) */
+int sim3opt_ba_chi2(sim3opt_ba* b, double* chi2);
+/* LM iterations performed (g2o's return convention: 0 on failure, -1 for an empty problem) */
+int sim3opt_ba_optimize(sim3opt_ba* b, int32_t max_iters);
+int sim3opt_ba_get_cameras(const sim3opt_ba* b, double* cam_qt /* n_cams x 7 */);
+int sim3opt_ba_get_points(const sim3opt_ba* b, double* points /* n_points x 3 */);
+int32_t sim3opt_ba_num_iterations(const sim3opt_ba* b);
+int sim3opt_ba_get_stats(const sim3opt_ba* b, int32_t iter, sim3opt_iter_stats* out);
+/* "% SE3 optimization result: kf id, tcinw, rc2w(qxyzw)" rows                        :223-238 */
+int sim3opt_ba_write_poses(const sim3opt_ba* b, const char* path);
+
 /* ---- stepwise optimisation, stage 1 (host C++) ----
  * "scale_dlt" of testStepwiseSim3Optimization                        kitti_surf.cpp:887-933
  * Null vector of the edge equations s_C x[v0] - x[v1] = 0 (the reference: last column of V of

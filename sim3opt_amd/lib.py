@@ -56,6 +56,21 @@ class IterStats(C.Structure):
     ]
 
 
+class BaOptions(C.Structure):
+    """sim3opt_ba_options (include/sim3opt.h), field for field."""
+    _fields_ = [
+        ("huber_delta", C.c_double),
+        ("pixel_noise", C.c_double),
+        ("tau", C.c_double),
+        ("user_lambda_init", C.c_double),
+        ("max_trials", C.c_int32),
+        ("pcg_max_iters", C.c_int32),
+        ("pcg_rel_tol", C.c_double),
+        ("device", C.c_int32),
+        ("verbose", C.c_int32),
+    ]
+
+
 class KernelTimes(C.Structure):
     _fields_ = [
         ("ms_spmv", C.c_double), ("n_spmv", C.c_int64),
@@ -128,6 +143,22 @@ SYMBOLS = {
     "sim3opt_write_g2o": (C.c_int, [_vp, C.c_char_p]),
     "sim3opt_write_bal": (C.c_int, [C.c_char_p, C.c_int32, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip, _dp]),
     "sim3opt_align_trajectory": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _dp]),
+    "sim3opt_ba_options_default": (None, [C.POINTER(BaOptions)]),
+    "sim3opt_ba_create": (_vp, []),
+    "sim3opt_ba_destroy": (None, [_vp]),
+    "sim3opt_ba_last_error": (C.c_char_p, [_vp]),
+    "sim3opt_ba_set_options": (C.c_int, [_vp, C.POINTER(BaOptions)]),
+    "sim3opt_ba_set_problem": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip, _dp,
+                                         C.c_double, C.c_double, C.c_double]),
+    "sim3opt_ba_read_bal": (C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double, C.c_double]),
+    "sim3opt_ba_dims": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "sim3opt_ba_chi2": (C.c_int, [_vp, _dp]),
+    "sim3opt_ba_optimize": (C.c_int, [_vp, C.c_int32]),
+    "sim3opt_ba_get_cameras": (C.c_int, [_vp, _dp]),
+    "sim3opt_ba_get_points": (C.c_int, [_vp, _dp]),
+    "sim3opt_ba_num_iterations": (C.c_int32, [_vp]),
+    "sim3opt_ba_get_stats": (C.c_int, [_vp, C.c_int32, C.POINTER(IterStats)]),
+    "sim3opt_ba_write_poses": (C.c_int, [_vp, C.c_char_p]),
 }
 
 _lib = None
@@ -526,6 +557,103 @@ def write_bal(path, Rw2c, tw2c, f_k1_k2, points, obs_cam, obs_point, obs_uv):
                                   _p(uv, _dp))
     if rc != OK:
         raise Sim3OptError(rc, "write_bal")
+
+
+# KITTI calibration the reference hard-codes for ba_demo (bal_example.cpp:90-91, kitti_surf.cpp:52-57)
+KITTI_FOCAL, KITTI_CX, KITTI_CY = 718.856, 607.1928, 185.2157
+
+
+class BundleAdjuster:
+    """sim3opt_ba*: the reference's ba_demo (bal_example.cpp:44-243) -- SE(3) cameras + points, Huber,
+    LM over the Schur complement -- on the GPU.  Mirrors the demo's flow: read a BAL file (or hand the
+    arrays over), optimize(maxIterations), write the camera poses."""
+
+    def __init__(self, **options):
+        self._L = load()
+        self._b = self._L.sim3opt_ba_create()
+        if not self._b:
+            raise MemoryError("sim3opt_ba_create")
+        if options:
+            self.set_options(**options)
+
+    def close(self):
+        if self._b:
+            self._L.sim3opt_ba_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != OK:
+            raise Sim3OptError(rc, f"{what}: {self._L.sim3opt_ba_last_error(self._b).decode()}")
+
+    def set_options(self, **kw):
+        o = BaOptions()
+        self._L.sim3opt_ba_options_default(C.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        self._chk(self._L.sim3opt_ba_set_options(self._b, C.byref(o)), "ba_set_options")
+
+    def set_problem(self, cams, points, obs_cam, obs_point, obs_uv, focal=KITTI_FOCAL, cx=KITTI_CX,
+                    cy=KITTI_CY):
+        cq, pts = _f64(cams).reshape(-1, 7), _f64(points).reshape(-1, 3)
+        oc, op, uv = _i32(obs_cam), _i32(obs_point), _f64(obs_uv).reshape(-1, 2)
+        if not (oc.shape[0] == op.shape[0] == uv.shape[0]):
+            raise ValueError("observation arrays differ in length")
+        self._chk(self._L.sim3opt_ba_set_problem(self._b, cq.shape[0], _p(cq, _dp), pts.shape[0],
+                                                 _p(pts, _dp), oc.shape[0], _p(oc, _ip), _p(op, _ip),
+                                                 _p(uv, _dp), focal, cx, cy), "ba_set_problem")
+
+    def read_bal(self, path, focal=KITTI_FOCAL, cx=KITTI_CX, cy=KITTI_CY):
+        self._chk(self._L.sim3opt_ba_read_bal(self._b, os.fsencode(path), focal, cx, cy), "ba_read_bal")
+
+    def dims(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.sim3opt_ba_dims(self._b, C.byref(a), C.byref(b), C.byref(c)), "ba_dims")
+        return a.value, b.value, c.value
+
+    def chi2(self):
+        v = C.c_double()
+        self._chk(self._L.sim3opt_ba_chi2(self._b, C.byref(v)), "ba_chi2")
+        return v.value
+
+    def optimize(self, max_iters=5):
+        """LM iterations performed (0 = failure, as g2o); raises when the library reports an error."""
+        n = self._L.sim3opt_ba_optimize(self._b, int(max_iters))
+        if n <= 0:
+            msg = self._L.sim3opt_ba_last_error(self._b).decode()
+            if msg:
+                raise Sim3OptError(n, f"ba_optimize: {msg}")
+        return n
+
+    def cameras(self):
+        nc = self.dims()[0]
+        out = np.empty((nc, 7))
+        self._chk(self._L.sim3opt_ba_get_cameras(self._b, _p(out, _dp)), "ba_get_cameras")
+        return out
+
+    def points(self):
+        n = self.dims()[1]
+        out = np.empty((n, 3))
+        self._chk(self._L.sim3opt_ba_get_points(self._b, _p(out, _dp)), "ba_get_points")
+        return out
+
+    def stats(self):
+        out = []
+        for i in range(self._L.sim3opt_ba_num_iterations(self._b)):
+            st = IterStats()
+            self._chk(self._L.sim3opt_ba_get_stats(self._b, i, C.byref(st)), "ba_get_stats")
+            out.append({k: getattr(st, k) for k, _ in IterStats._fields_})
+        return out
+
+    def write_poses(self, path):
+        self._chk(self._L.sim3opt_ba_write_poses(self._b, os.fsencode(path)), "ba_write_poses")
 
 
 def align_trajectory(query_xyz, train_xyz, with_scale=True):
