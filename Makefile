@@ -3,6 +3,7 @@
 #   make example         -> examples/direct_pgo (testDirectSim3Optimization on the g2o-named shim)
 #   make call_forms      -> tests/cxx/reference_call_forms (the reference's call forms against the
 #                           shim; EIGEN_INC=-I/usr/include/eigen3 for a real Eigen + Sophus)
+#   make ba_call_forms   -> tests/cxx/reference_ba_call_forms (ba_demo's call forms against the BA shim)
 #   make LIB=/some/where/libsim3opt.so   builds the library elsewhere (used by the tests)
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := sim3opt_amd/csrc
@@ -29,7 +30,12 @@ call_forms: $(LIB) tests/cxx/reference_call_forms.cpp include/sim3opt_g2o.hpp
 	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude $(EIGEN_INC) tests/cxx/reference_call_forms.cpp \
 	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/reference_call_forms
 
-clean:
-	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo tests/cxx/reference_call_forms
+ba_call_forms: $(LIB) tests/cxx/reference_ba_call_forms.cpp include/sim3opt_g2o_ba.hpp
+	g++ -std=c++17 -Wall -DSIM3OPT_G2O_BA_NAMES -Iinclude $(EIGEN_INC) tests/cxx/reference_ba_call_forms.cpp \
+	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/reference_ba_call_forms
 
-.PHONY: all example call_forms clean
+clean:
+	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo tests/cxx/reference_call_forms \
+	    tests/cxx/reference_ba_call_forms
+
+.PHONY: all example call_forms ba_call_forms clean

@@ -336,6 +336,9 @@ int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, 
                            const double* points, int32_t n_obs, const int32_t* obs_cam,
                            const int32_t* obs_point, const double* obs_uv, double focal, double cx,
                            double cy);
+/* OptimizableGraph::Vertex::setFixed on cameras (n_cams flags; ba_demo itself fixes none).  A fixed
+ * camera keeps its estimate and leaves the linear system. */
+int sim3opt_ba_set_fixed_cameras(sim3opt_ba* b, const uint8_t* fixed);
 /* the BAL file ba_demo takes as argv[1] (:104-189; per-camera f, k1, k2 are read and ignored as
  * there: the projection uses the fixed focal / cx / cy) */
 int sim3opt_ba_read_bal(sim3opt_ba* b, const char* path, double focal, double cx, double cy);

@@ -111,6 +111,7 @@ class Problem:
         self.uv = np.asarray(obs_uv, dtype=np.float64).reshape(-1, 2)
         self.f, self.cx, self.cy = float(focal), float(cx), float(cy)
         self.huber, self.omega = float(huber), 1.0 / float(pixel_noise) ** 2
+        self.fixed = np.zeros(len(self.cams), dtype=bool)  # Vertex::setFixed on cameras
 
     # EdgeProjectXYZ2UV::computeError: obs - cam_map(T.map(p))
     def _camera_frame(self, cams, points):
@@ -189,6 +190,12 @@ class Problem:
         np.add.at(b, oc6[:, None] + np.arange(6), -np.einsum("nri,nr->ni", JcW, e))
         np.add.at(b, op3[:, None] + np.arange(3), -np.einsum("nri,nr->ni", JpW, e))
         H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsc()
+        if self.fixed.any():  # fixed cameras leave the system: identity rows, zero right-hand side
+            keep = np.ones(n)
+            keep[(6 * np.where(self.fixed)[0][:, None] + np.arange(6)).ravel()] = 0.0
+            D = sp.diags(keep)
+            H = (D @ H @ D + sp.diags(1.0 - keep)).tocsc()
+            b = b * keep
         return H, b, float(rho.sum())
 
     def apply(self, cams, points, dx):
@@ -198,20 +205,39 @@ class Problem:
         tn = np.einsum("nij,nj->ni", R, cams[:, 4:7]) + t
         q = R_to_quat(Rn)
         q /= np.linalg.norm(q, axis=1, keepdims=True)
-        return np.concatenate([q, tn], axis=1), points + dx[6 * nc:].reshape(-1, 3)
+        new = np.concatenate([q, tn], axis=1)
+        new[self.fixed] = cams[self.fixed]
+        return new, points + dx[6 * nc:].reshape(-1, 3)
 
-    def optimize(self, iters, tau=1e-5, max_trials=10, lam0=0.0):
+    def solve(self, H, b, lam, schur=False):
+        """(H + lam I) dx = b.  schur=False: one sparse LU of the whole system (the independent check
+        of the GPU's Schur path); schur=True: BlockSolver_6_3's way -- eliminate the points (3x3 blocks),
+        solve the reduced camera system, back-substitute -- for problems of the KITTI map's size."""
+        n = H.shape[0]
+        if not schur:
+            return spla.spsolve(H + lam * sp.identity(n, format="csc"), b)
+        n6 = 6 * self.cams.shape[0]
+        Hl = (H + lam * sp.identity(n, format="csc")).tocsr()
+        A, B, D = Hl[:n6, :n6], Hl[:n6, n6:], Hl[n6:, n6:].tobsr(blocksize=(3, 3))
+        assert np.array_equal(D.indices, np.arange(D.shape[0] // 3))  # block diagonal
+        Dinv = sp.bsr_matrix((np.linalg.inv(D.data), D.indices, D.indptr), shape=D.shape).tocsr()
+        BD = B @ Dinv
+        dxc = spla.spsolve((A - BD @ B.T).tocsc(), b[:n6] - BD @ b[n6:])
+        return np.concatenate([dxc, Dinv @ (b[n6:] - B.T @ dxc)])
+
+    def optimize(self, iters, tau=1e-5, max_trials=10, lam0=0.0, schur=False):
         """OptimizationAlgorithmLevenberg on the BA graph; updates self in place."""
         trace = []
         lam = lam0 if lam0 > 0 else None
         for it in range(iters):
             H, b, chi_cur = self.system()
             if lam is None:
-                lam = tau * float(np.abs(H.diagonal()).max())
+                free = np.ones(H.shape[0], dtype=bool)
+                free[(6 * np.where(self.fixed)[0][:, None] + np.arange(6)).ravel()] = False
+                lam = tau * float(np.abs(H.diagonal()[free]).max())
             ni, q, rho = 2.0, 0, 0.0
-            I = sp.identity(H.shape[0], format="csc")
             while True:
-                dx = spla.spsolve(H + lam * I, b)
+                dx = self.solve(H, b, lam, schur)
                 cn, pn = self.apply(self.cams, self.points, dx)
                 chi_new = self.chi2(cn, pn)
                 scale = float(dx @ (lam * dx + b)) + 1e-3

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __re
                                                    const int32_t* __restrict__ op,
                                                    const double* __restrict__ lin,
                                                    const double* __restrict__ Z,
-                                                   const double* __restrict__ bp, double lambda,
+                                                   const double* __restrict__ bp,
+                                                   const uint8_t* __restrict__ fixed, double lambda,
                                                    double* __restrict__ S, double* __restrict__ g,
                                                    double* __restrict__ bc, double* __restrict__ cdmax) {
   const int lane = threadIdx.x & 63;
@@ -224,6 +225,15 @@ __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __re
   const int i = brow[k], j = bcol[k];
   const int l36 = lane < 36 ? lane : lane % 36;
   const int r = l36 / 6, c = l36 % 6;
+  if (fixed[i] | fixed[j]) {  // setFixed(true): the camera leaves the system (identity row, zero rhs)
+    if (lane < 36) S[(size_t)36 * k + lane] = (i == j && r == c) ? 1.0 : 0.0;
+    if (i == j && lane < 6) {
+      g[6 * (size_t)i + lane] = 0.0;
+      bc[6 * (size_t)i + lane] = 0.0;
+      cdmax[6 * (size_t)i + lane] = 0.0;
+    }
+    return;
+  }
   double acc = 0.0;
   for (int e = sptr[k]; e < sptr[k + 1]; ++e) {
     const double* z = Z + (size_t)18 * sa[e] + 3 * r;  // Z_o1 row r
@@ -415,11 +425,12 @@ __global__ __launch_bounds__(WG) void k_ba_backsub(int np, const int32_t* __rest
 
 // VertexSE3Expmap::oplusImpl: T <- SE3Quat::exp([omega, upsilon]) T; points: p += dx
 __global__ __launch_bounds__(WG) void k_ba_update(int nc, int np, const double* __restrict__ xc,
-                                                  const double* __restrict__ xp, Cam* cams, double* pts,
+                                                  const double* __restrict__ xp,
+                                                  const uint8_t* __restrict__ fixed, Cam* cams, double* pts,
                                                   const Scal* sc) {
   if (sc->pcg_fail) return;  // the host rejects the trial
   const int t = blockIdx.x * WG + threadIdx.x;
-  if (t < nc) {
+  if (t < nc && !fixed[t]) {
     const double* u = xc + (size_t)6 * t;
     const double th = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     const double Om[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
@@ -552,6 +563,7 @@ struct Problem {
   std::vector<Cam> cams;
   std::vector<double> pts;  // 3 per point
   std::vector<int32_t> oc, op;
+  std::vector<uint8_t> cam_fixed;
   std::vector<double> uv;
   double f = 718.856, cx = 607.1928, cy = 185.2157;  // kitti_surf.cpp:52-57, bal_example.cpp:90-91
   sim3opt_ba_options opt;
@@ -570,6 +582,7 @@ struct Problem {
   int32_t *d_oc = nullptr, *d_op = nullptr, *d_pptr = nullptr, *d_pobs = nullptr, *d_cptr = nullptr,
           *d_cobs = nullptr, *d_brow = nullptr, *d_bcol = nullptr, *d_sptr = nullptr, *d_sa = nullptr,
           *d_sb = nullptr, *d_rptr = nullptr;
+  uint8_t* d_fixed = nullptr;
   Scal *d_sc = nullptr, *h_sc = nullptr;
   int32_t nblk = 0;
   int grid_chi = 1;
@@ -675,6 +688,8 @@ struct Problem {
     BCHK(up(d_pptr, pptr)); BCHK(up(d_pobs, pobs)); BCHK(up(d_cptr, cptr)); BCHK(up(d_cobs, cobs));
     BCHK(up(d_brow, brow)); BCHK(up(d_bcol, bcol)); BCHK(up(d_sptr, sptr)); BCHK(up(d_sa, sa)); BCHK(up(d_sb, sb));
     BCHK(up(d_rptr, rptr));
+    cam_fixed.resize(NC, 0);
+    BCHK(up(d_fixed, cam_fixed));
     BCHK(alloc(d_lin, 20 * (size_t)NO)); BCHK(alloc(d_Z, 18 * (size_t)NO));
     BCHK(alloc(d_Hinv, 9 * (size_t)NP)); BCHK(alloc(d_bp, 3 * (size_t)NP)); BCHK(alloc(d_pdmax, NP));
     BCHK(alloc(d_cdmax, 6 * (size_t)NC));
@@ -739,7 +754,7 @@ struct Problem {
                              d_Hinv, d_bp, d_pdmax);
           hipLaunchKernelGGL(k_ba_obs2, dim3(go), dim3(WG), 0, stream, NO, d_op, d_lin, d_Hinv, d_Z);
           hipLaunchKernelGGL(k_ba_reduced, dim3((nblk + 3) / 4), dim3(WG), 0, stream, nblk, d_brow, d_bcol,
-                             d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, 1.0, d_S, d_g, d_bc,
+                             d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, d_fixed, 1.0, d_S, d_g, d_bc,
                              d_cdmax);
           hipLaunchKernelGGL(k_ba_final, dim3(1), dim3(WG), 0, stream, (const double*)nullptr, 0,
                              (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)d_pdmax, NP,
@@ -758,7 +773,7 @@ struct Problem {
                            d_Hinv, d_bp, d_pdmax);
         hipLaunchKernelGGL(k_ba_obs2, dim3(go), dim3(WG), 0, stream, NO, d_op, d_lin, d_Hinv, d_Z);
         hipLaunchKernelGGL(k_ba_reduced, dim3((nblk + 3) / 4), dim3(WG), 0, stream, nblk, d_brow, d_bcol,
-                           d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, lambda, d_S, d_g, d_bc,
+                           d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, d_fixed, lambda, d_S, d_g, d_bc,
                            d_cdmax);
         hipLaunchKernelGGL(k_ba_pcg, dim3(1), dim3(1024), 0, stream, NC, d_rptr, d_bcol, d_S, d_g, d_xc, d_r,
                            d_z, d_p, d_q, d_Dinv, opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 20 * NC + 100,
@@ -766,7 +781,7 @@ struct Problem {
         hipLaunchKernelGGL(k_ba_backsub, dim3(gp), dim3(WG), 0, stream, NP, d_pptr, d_pobs, d_oc, d_Hinv,
                            d_bp, d_Z, d_xc, d_xp);
         hipLaunchKernelGGL(k_ba_update, dim3((std::max(NC, 3 * NP) + WG - 1) / WG), dim3(WG), 0, stream, NC, NP,
-                           d_xc, d_xp, d_cams, d_pts, (const Scal*)d_sc);
+                           d_xc, d_xp, d_fixed, d_cams, d_pts, (const Scal*)d_sc);
         // scale = x.(lambda x + b) over cameras and points
         const int gsc = std::max(1, std::min(1024, (6 * NC + WG - 1) / WG));
         const int gsp = std::max(1, std::min(1024, (3 * NP + WG - 1) / WG));
@@ -891,7 +906,17 @@ int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, 
   b->op.assign(obs_point, obs_point + n_obs);
   b->uv.assign(obs_uv, obs_uv + 2 * (size_t)n_obs);
   b->f = focal; b->cx = cx; b->cy = cy;
+  b->cam_fixed.assign(n_cams, 0);
   b->stats.clear();
+  return SIM3OPT_OK;
+}
+
+int sim3opt_ba_set_fixed_cameras(sim3opt_ba* b, const uint8_t* fixed) {
+  if (!b || !fixed) return SIM3OPT_ERR_ARG;
+  if (b->nc() < 1) { b->err = "ba_set_fixed_cameras: no problem set"; return SIM3OPT_ERR_STATE; }
+  b->cam_fixed.assign(fixed, fixed + b->nc());
+  for (auto& f : b->cam_fixed) f = f ? 1 : 0;
+  b->release();  // the next call re-uploads
   return SIM3OPT_OK;
 }
 

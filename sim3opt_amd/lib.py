@@ -150,6 +150,7 @@ SYMBOLS = {
     "sim3opt_ba_set_options": (C.c_int, [_vp, C.POINTER(BaOptions)]),
     "sim3opt_ba_set_problem": (C.c_int, [_vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip, _dp,
                                          C.c_double, C.c_double, C.c_double]),
+    "sim3opt_ba_set_fixed_cameras": (C.c_int, [_vp, _up]),
     "sim3opt_ba_read_bal": (C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double, C.c_double]),
     "sim3opt_ba_dims": (C.c_int, [_vp, _ip, _ip, _ip]),
     "sim3opt_ba_chi2": (C.c_int, [_vp, _dp]),
@@ -609,6 +610,12 @@ class BundleAdjuster:
         self._chk(self._L.sim3opt_ba_set_problem(self._b, cq.shape[0], _p(cq, _dp), pts.shape[0],
                                                  _p(pts, _dp), oc.shape[0], _p(oc, _ip), _p(op, _ip),
                                                  _p(uv, _dp), focal, cx, cy), "ba_set_problem")
+
+    def set_fixed_cameras(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape[0] != self.dims()[0]:
+            raise ValueError("one flag per camera")
+        self._chk(self._L.sim3opt_ba_set_fixed_cameras(self._b, _p(m, _up)), "ba_set_fixed_cameras")
 
     def read_bal(self, path, focal=KITTI_FOCAL, cx=KITTI_CX, cy=KITTI_CY):
         self._chk(self._L.sim3opt_ba_read_bal(self._b, os.fsencode(path), focal, cx, cy), "ba_read_bal")

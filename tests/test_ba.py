@@ -101,6 +101,14 @@ def test_oracle_huber_and_lm_decrease():
     assert all(b <= a for a, b in zip(chis, chis[1:])) and chis[-1] < 0.2 * c0
 
 
+def test_oracle_schur_solve_equals_full_solve():
+    P, _ = synthetic_problem(n_cams=7, n_points=200, seed=9)
+    P.fixed[0] = True
+    H, b, _ = P.system()
+    full, red = P.solve(H, b, 2.5), P.solve(H, b, 2.5, schur=True)
+    assert np.abs(full - red).max() < 1e-9 * np.abs(full).max()
+
+
 def test_bal_reader_matches_writer(tmp_path):
     cams, points, oc, op, uv, R, t = keyframe_problem()
     path = str(tmp_path / "kf.txt")
@@ -180,6 +188,29 @@ def test_gpu_lm_trace_matches_oracle(seed, n_cams, n_points):
     assert quat_dist(b.cameras()[:, :4], P.cams[:, :4]) < 1e-8
     assert np.abs(b.cameras()[:, 4:] - P.cams[:, 4:]).max() < 1e-7
     assert np.abs(b.points() - P.points).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_fixed_cameras_keep_their_pose_and_match_oracle():
+    """Vertex::setFixed on the first two cameras (the usual gauge anchor; ba_demo itself fixes none)."""
+    P, _ = synthetic_problem(n_cams=9, n_points=300, seed=21)
+    mask = np.zeros(9, dtype=np.uint8)
+    mask[:2] = 1
+    P.fixed = mask.astype(bool)
+    start = P.cams.copy()
+    b = gpu_problem(P)
+    b.set_fixed_cameras(mask)
+    before = b.cameras()  # (set_problem renormalises the quaternions: last-bit differences from `start`)
+    n = b.optimize(5)
+    tr = P.optimize(5)
+    assert n == len(tr)
+    for s, t in zip(b.stats(), tr):
+        assert s["trials"] == t["trials"] and abs(s["chi2_after"] - t["chi2"]) <= 1e-7 * t["chi2"]
+    got = b.cameras()
+    assert np.array_equal(got[:2], before[:2]) and np.abs(before - start).max() < 1e-15 and np.abs(got[2:] - start[2:]).max() > 1e-4
+    assert quat_dist(got[:, :4], P.cams[:, :4]) < 1e-8 and np.abs(got[:, 4:] - P.cams[:, 4:]).max() < 1e-7
+    with pytest.raises(ValueError):
+        b.set_fixed_cameras(mask[:3])
 
 
 @pytest.mark.gpu

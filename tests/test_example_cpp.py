@@ -89,6 +89,72 @@ def test_reference_call_forms_compile_against_real_eigen(tmp_path):
     compile_call_forms(tmp_path, ["-I" + inc[0]] + MOCK)
 
 
+def compile_ba_call_forms(tmp_path, eigen_inc):
+    exe = str(tmp_path / "reference_ba_call_forms")
+    libdir = os.path.join(ROOT, "sim3opt_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-DSIM3OPT_G2O_BA_NAMES",
+                           "-I" + os.path.join(ROOT, "include")] + eigen_inc +
+                          [os.path.join(ROOT, "tests", "cxx", "reference_ba_call_forms.cpp"), "-L" + libdir,
+                           "-lsim3opt", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def write_keyframe_bal(tmp_path):
+    """The three fixture keyframes as a BAL file (drawPTAMPoints.cpp:218-283, :333-371)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tests import test_ba as TB
+    from sim3opt_amd import lib as L
+    cams, points, oc, op, uv, R, t = TB.keyframe_problem()
+    path = str(tmp_path / "kf.bal")
+    L.write_bal(path, R.reshape(-1, 9), t, [718.856, 0, 0], points, oc, op, uv)
+    return path
+
+
+def test_ba_call_forms_compile_against_the_mock(tmp_path):
+    """ba_demo's forms (bal_example.cpp:71-238) -- BlockSolver_6_3, CameraParameters, VertexSE3Expmap,
+    VertexSBAPointXYZ, EdgeProjectXYZ2UV + RobustKernelHuber, SE3Quat -- compile (-Werror) and link
+    against include/sim3opt_g2o_ba.hpp; without a GPU the program fails loudly."""
+    import torch
+    exe = compile_ba_call_forms(tmp_path, MOCK)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe, write_keyframe_bal(tmp_path), str(tmp_path / "poses.txt")], capture_output=True, text=True)
+    assert r.returncode == 3 and "optimize failed" in r.stderr or "initializeOptimization failed" in r.stderr
+
+
+def test_ba_call_forms_compile_against_real_eigen(tmp_path):
+    inc = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3")
+           if os.path.exists(os.path.join(d, "Eigen", "Core"))]
+    if not inc:
+        pytest.skip("no Eigen in this image (SURVEY.md 0.2): the mock stands in")
+    compile_ba_call_forms(tmp_path, ["-I" + inc[0]])
+
+
+@pytest.mark.gpu
+def test_ba_call_forms_run(tmp_path):
+    """The g2o-named builder and the C-ABI / Python path give the same optimisation."""
+    import re
+    from sim3opt_amd import lib as L
+    exe = compile_ba_call_forms(tmp_path, MOCK)
+    bal = write_keyframe_bal(tmp_path)
+    out = str(tmp_path / "poses.txt")
+    r = subprocess.run([exe, bal, out, "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    m = re.search(r"ba: chi2 (\S+) -> (\S+) in (\d+) iterations", r.stdout)
+    b = L.BundleAdjuster()
+    b.read_bal(bal)
+    c0 = b.chi2()
+    n = b.optimize(5)
+    assert m and int(m.group(3)) == n
+    assert abs(float(m.group(1)) - c0) < 1e-9 * c0 and abs(float(m.group(2)) - b.chi2()) < 1e-7 * c0
+    want = str(tmp_path / "poses_capi.txt")
+    b.write_poses(want)
+    A = np.loadtxt(out, comments="%")
+    B = np.loadtxt(want, comments="%")
+    assert A.shape == B.shape == (3, 8) and np.abs(A - B).max() < 1e-8
+
+
 def test_makefile_builds_a_loadable_library(tmp_path):
     """`make` (the documented non-Python build) must produce the same library as build.py: every
     translation unit linked, every symbol of include/sim3opt.h exported."""
