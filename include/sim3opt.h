@@ -320,6 +320,9 @@ typedef struct sim3opt_ba_options {
   int32_t max_trials;       /* LM trials per iteration                             default 10        */
   int32_t pcg_max_iters;    /* reduced camera system; 0 = automatic                default 0         */
   double pcg_rel_tol;       /* |r|_M / |r0|_M of the reduced system                default 1e-12     */
+  int32_t linear_solver;    /* reduced camera system: -1 automatic (exact block Cholesky unless one
+                               factorisation needs > 8 M block products), 1 exact or fail, 0 block-Jacobi
+                               PCG                                                 default -1   :76-80 */
   int32_t device;           /* HIP device ordinal, -1 = current                    default -1        */
   int32_t verbose;          /* one line per LM iteration on stderr                 default 0    :72  */
 } sim3opt_ba_options;

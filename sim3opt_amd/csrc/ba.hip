@@ -18,8 +18,11 @@
 //   k_ba_reduced  wavefront / block (i,j) of the reduced camera system: S_ij = [i=j](lambda I + sum
 //                 A^T A) - sum over the listed observation pairs Z_o1 (A^T B)_o2^T; the diagonal block's
 //                 wavefront also forms g_i = b_c,i - sum Z_o b_p(o)
-//   k_ba_pcg      ONE workgroup: block-Jacobi PCG on S dx_c = g (771 cameras = 4626 unknowns on
-//                 KITTI-00: a handful of MB per pass, not worth a launch per step)
+//   k_ldl*        the reduced camera system S dx_c = g solved exactly: the level-scheduled block
+//                 Cholesky of direct.hpp / direct_kernels.hpp (written for the 7x7 blocks of the
+//                 Sim(3) graphs; the 6x6 camera blocks are stored padded to 7x7 with a unit diagonal
+//                 entry, which leaves the factorisation of the 6x6 part untouched)
+//   k_ba_pcg      fallback when a factorisation would be too large: block-Jacobi PCG in ONE workgroup
 //   k_ba_backsub  thread / point: dx_p = H_pp^-1 b_p - sum Z_o^T dx_c(cam(o))
 //   k_ba_update   exp-map update of the cameras, additive update of the points (backup kept)
 //   k_ba_chi2     thread / observation: robustified chi2, fixed-order block sums
@@ -36,6 +39,7 @@
 #include <vector>
 
 #include "../../include/sim3opt.h"
+#include "direct.hpp"
 
 namespace sim3opt_bundle {
 
@@ -56,9 +60,14 @@ struct Cam {  // T_w2c: unit quaternion (x y z w) and translation; 8th double pa
 
 struct Scal {
   double chi2, scale, maxdiag;
-  int32_t pcg_iters, pcg_fail;
+  int32_t pcg_iters, fail;  // fail: PCG breakdown or a non-positive pivot of the factorisation
   double pcg_rel;
 };
+
+// the exact block Cholesky kernels, instantiated for this translation unit
+using DevScalars = Scal;
+using sim3opt::DirectPlan;
+#include "direct_kernels.hpp"
 
 __device__ __forceinline__ void quat_to_R(const double q[4], double R[9]) {
   const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -204,7 +213,10 @@ __global__ __launch_bounds__(WG) void k_ba_obs2(int n_obs, const int32_t* __rest
   }
 }
 
-// reduced camera system: one wavefront per block k = (row i, column j); lane l < 36 = entry (r, c)
+// reduced camera system: one wavefront per block k = (row i, column j), stored as a 7x7 column-major
+// block (entry (r, c) at r + 7c) whose 6x6 part is S_ij and whose 7th row / column is that of the
+// identity; camera vectors are 7 per camera with a zero pad.  Lane l < 49 = entry l; lanes 49..54
+// build b_c and g of the diagonal block's camera.
 __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __restrict__ brow,
                                                    const int32_t* __restrict__ bcol,
                                                    const int32_t* __restrict__ sptr,
@@ -223,57 +235,62 @@ __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __re
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= nblk) return;
   const int i = brow[k], j = bcol[k];
-  const int l36 = lane < 36 ? lane : lane % 36;
-  const int r = l36 / 6, c = l36 % 6;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int r = l49 % 7, c = l49 / 7;
+  const bool pad = r == 6 || c == 6;
+  const int r6 = r < 6 ? r : 0, c6 = c < 6 ? c : 0;
   if (fixed[i] | fixed[j]) {  // setFixed(true): the camera leaves the system (identity row, zero rhs)
-    if (lane < 36) S[(size_t)36 * k + lane] = (i == j && r == c) ? 1.0 : 0.0;
-    if (i == j && lane < 6) {
-      g[6 * (size_t)i + lane] = 0.0;
-      bc[6 * (size_t)i + lane] = 0.0;
-      cdmax[6 * (size_t)i + lane] = 0.0;
+    if (lane < 49) S[(size_t)49 * k + lane] = (i == j && r == c) ? 1.0 : 0.0;
+    if (i == j && lane < 7) {
+      g[7 * (size_t)i + lane] = 0.0;
+      bc[7 * (size_t)i + lane] = 0.0;
+      cdmax[7 * (size_t)i + lane] = 0.0;
     }
     return;
   }
   double acc = 0.0;
   for (int e = sptr[k]; e < sptr[k + 1]; ++e) {
-    const double* z = Z + (size_t)18 * sa[e] + 3 * r;  // Z_o1 row r
-    const double* d = lin + (size_t)20 * sb[e];         // Y_o2 row c = (A^T B) row c
-    const double y0 = d[c] * d[12] + d[6 + c] * d[15];
-    const double y1 = d[c] * d[13] + d[6 + c] * d[16];
-    const double y2 = d[c] * d[14] + d[6 + c] * d[17];
+    const double* z = Z + (size_t)18 * sa[e] + 3 * r6;  // Z_o1 row r
+    const double* d = lin + (size_t)20 * sb[e];          // Y_o2 row c = (A^T B) row c
+    const double y0 = d[c6] * d[12] + d[6 + c6] * d[15];
+    const double y1 = d[c6] * d[13] + d[6 + c6] * d[16];
+    const double y2 = d[c6] * d[14] + d[6 + c6] * d[17];
     acc -= z[0] * y0 + z[1] * y1 + z[2] * y2;
   }
   if (i == j) {
-    double hd = 0.0, gb = 0.0, bcv = 0.0;  // lanes 36..41 build b_c and g for component lane - 36
-    const int comp = lane - 36;
+    double hd = 0.0, gb = 0.0, bcv = 0.0;
+    const int comp = lane - 49;  // lanes 49..54
+    const bool rhs = comp >= 0 && comp < 6;
+    const int cm = rhs ? comp : 0;
     for (int e = cptr[i]; e < cptr[i + 1]; ++e) {
       const int o = cobs[e];
       const double* d = lin + (size_t)20 * o;
-      hd += d[r] * d[c] + d[6 + r] * d[6 + c];
-      if (lane >= 36 && lane < 42) {
-        bcv -= d[comp] * d[18] + d[6 + comp] * d[19];
-        const double* z = Z + (size_t)18 * o + 3 * comp;
+      hd += d[r6] * d[c6] + d[6 + r6] * d[6 + c6];
+      if (rhs) {
+        bcv -= d[cm] * d[18] + d[6 + cm] * d[19];
+        const double* z = Z + (size_t)18 * o + 3 * cm;
         const double* b3 = bp + (size_t)3 * op[o];
         gb -= z[0] * b3[0] + z[1] * b3[1] + z[2] * b3[2];
       }
     }
-    if (lane < 36 && r == c) {
-      // undamped diagonal for lambda_0 (computeLambdaInit looks at every vertex's Hessian diagonal)
-      double m = hd;
-      cdmax[6 * (size_t)i + r] = m;
-    }
+    // undamped diagonal for lambda_0 (computeLambdaInit looks at every vertex's Hessian diagonal)
+    if (lane < 49 && r == c) cdmax[7 * (size_t)i + r] = pad ? 0.0 : hd;
     acc += hd + (r == c ? lambda : 0.0);
-    if (lane >= 36 && lane < 42) {
-      bc[6 * (size_t)i + comp] = bcv;
-      g[6 * (size_t)i + comp] = bcv + gb;
+    if (rhs) {
+      bc[7 * (size_t)i + comp] = bcv;
+      g[7 * (size_t)i + comp] = bcv + gb;
+    }
+    if (comp == 6) {
+      bc[7 * (size_t)i + 6] = 0.0;
+      g[7 * (size_t)i + 6] = 0.0;
     }
   }
-  if (lane < 36) S[(size_t)36 * k + lane] = acc;  // row-major 6x6
+  if (lane < 49) S[(size_t)49 * k + lane] = pad ? ((i == j && r == c) ? 1.0 : 0.0) : acc;
 }
 
-// block-Jacobi PCG on S x = g inside ONE workgroup (rows = cameras, 6x6 blocks, block-CSR with the
-// diagonal block first in every row).  Wavefront per block row in the SpMV, thread per unknown in
-// the vector steps; dot products through LDS in a fixed order.
+// Fallback: block-Jacobi PCG on S x = g inside ONE workgroup (rows = cameras, padded 7x7 blocks,
+// block-CSR with the diagonal block first in every row).  Wavefront per block row in the SpMV, thread
+// per unknown in the vector steps; dot products through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restrict__ rptr,
                                                  const int32_t* __restrict__ cidx,
                                                  const double* __restrict__ S,
@@ -283,9 +300,8 @@ __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restri
                                                  double* __restrict__ Dinv, int max_iter, double tol2,
                                                  Scal* sc) {
   __shared__ double red[1024];
-  __shared__ double bcast[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int n = 6 * nc;
+  const int n = 7 * nc;
   auto dot = [&](const double* a, const double* b) {
     double s = 0.0;
     for (int i = tid; i < n; i += blockDim.x) s += a[i] * b[i];
@@ -299,40 +315,40 @@ __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restri
     __syncthreads();
     return v;
   };
-  // D^-1: thread per camera, Gauss-Jordan on the diagonal block
+  // D^-1: thread per camera, Gauss-Jordan on the diagonal block (stored row-major here)
   bool spd = true;
   for (int i = tid; i < nc; i += blockDim.x) {
-    double a[6][6];
-    const double* blk = S + (size_t)36 * rptr[i];
+    double a[7][7];
+    const double* blk = S + (size_t)49 * rptr[i];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 7; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a[r][c] = blk[6 * r + c];
+      for (int c = 0; c < 7; ++c) a[r][c] = blk[r + 7 * c];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
       if (!(a[k][k] > 0.0)) spd = false;
       const double d = 1.0 / a[k][k];
 #pragma unroll
-      for (int jj = 0; jj < 6; ++jj)
+      for (int jj = 0; jj < 7; ++jj)
         if (jj != k) a[k][jj] *= d;
 #pragma unroll
-      for (int ii = 0; ii < 6; ++ii)
+      for (int ii = 0; ii < 7; ++ii)
         if (ii != k) {
           const double f = a[ii][k];
 #pragma unroll
-          for (int jj = 0; jj < 6; ++jj)
+          for (int jj = 0; jj < 7; ++jj)
             if (jj != k) a[ii][jj] -= f * a[k][jj];
           a[ii][k] = -f * d;
         }
       a[k][k] = d;
     }
-    double* dst = Dinv + (size_t)36 * i;
+    double* dst = Dinv + (size_t)49 * i;
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 7; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) dst[6 * r + c] = a[r][c];
+      for (int c = 0; c < 7; ++c) dst[7 * r + c] = a[r][c];
   }
-  if (!spd) sc->pcg_fail = 1;
+  if (!spd) sc->fail = 1;
   for (int i = tid; i < n; i += blockDim.x) {
     x[i] = 0.0;
     rv[i] = g[i];
@@ -340,10 +356,10 @@ __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restri
   __syncthreads();
   auto precond = [&]() {  // z = D^-1 r
     for (int i = tid; i < n; i += blockDim.x) {
-      const int cam = i / 6, rr = i % 6;
-      const double* d = Dinv + (size_t)36 * cam + 6 * rr;
-      const double* rr6 = rv + (size_t)6 * cam;
-      zv[i] = d[0] * rr6[0] + d[1] * rr6[1] + d[2] * rr6[2] + d[3] * rr6[3] + d[4] * rr6[4] + d[5] * rr6[5];
+      const int cam = i / 7, rr = i % 7;
+      const double* d = Dinv + (size_t)49 * cam + 7 * rr;
+      const double* r7 = rv + (size_t)7 * cam;
+      zv[i] = d[0] * r7[0] + d[1] * r7[1] + d[2] * r7[2] + d[3] * r7[3] + d[4] * r7[4] + d[5] * r7[5] + d[6] * r7[6];
     }
     __syncthreads();
   };
@@ -354,19 +370,16 @@ __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restri
   const double rz0 = rz;
   int it = 0;
   bool fail = false;
+  const int l49 = lane < 49 ? lane : lane - 49;
+  const int r = l49 % 7, c = l49 / 7;
   while (it < max_iter && rz > tol2 * rz0 && rz > 0.0) {
-    // q = S p : wavefront per block row, lane (r, c) of the 6x6 block
+    // q = S p : wavefront per block row, lane = entry (r, c) of the column-major block
     for (int row = wave; row < nc; row += nw) {
-      const int r = (lane % 36) / 6, c = (lane % 36) % 6;
       double acc = 0.0;
       for (int k = rptr[row]; k < rptr[row + 1]; ++k)
-        if (lane < 36) acc += S[(size_t)36 * k + 6 * r + c] * pv[(size_t)6 * cidx[k] + c];
-      // sum over c within groups of 6 lanes
-      double s = acc;
-      s += __shfl_down(s, 1);
-      const double s2 = s + __shfl_down(s, 2);
-      const double s3 = s2 + __shfl_down(s, 4);  // lanes c = 0: acc0+acc1 + acc2+acc3 + acc4+acc5
-      if (lane < 36 && c == 0) qv[(size_t)6 * row + r] = s3;
+        acc += S[(size_t)49 * k + l49] * pv[(size_t)7 * cidx[k] + c];
+      const double s = ldl_sum_over_c(lane < 49 ? acc : 0.0, r);
+      if (lane < 7) qv[(size_t)7 * row + lane] = s;
     }
     __syncthreads();
     const double pq = dot(pv, qv);
@@ -387,10 +400,9 @@ __global__ __launch_bounds__(1024) void k_ba_pcg(int nc, const int32_t* __restri
   }
   if (tid == 0) {
     sc->pcg_iters = it;
-    if (fail || !(rz >= 0.0)) sc->pcg_fail = 1;
+    if (fail || !(rz >= 0.0)) sc->fail = 1;
     sc->pcg_rel = rz0 > 0 ? sqrt(fabs(rz) / rz0) : 0.0;
   }
-  (void)bcast;
 }
 
 // per point: dx_p = Hinv b_p - sum_o Z_o^T dx_c(cam(o))
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(WG) void k_ba_backsub(int np, const int32_t* __rest
   for (int k = pptr[p]; k < pptr[p + 1]; ++k) {
     const int o = pobs[k];
     const double* z = Z + (size_t)18 * o;
-    const double* x6 = xc + (size_t)6 * oc[o];
+    const double* x6 = xc + (size_t)7 * oc[o];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double s = 0.0;
@@ -428,10 +440,10 @@ __global__ __launch_bounds__(WG) void k_ba_update(int nc, int np, const double* 
                                                   const double* __restrict__ xp,
                                                   const uint8_t* __restrict__ fixed, Cam* cams, double* pts,
                                                   const Scal* sc) {
-  if (sc->pcg_fail) return;  // the host rejects the trial
+  if (sc->fail) return;  // the host rejects the trial
   const int t = blockIdx.x * WG + threadIdx.x;
   if (t < nc && !fixed[t]) {
-    const double* u = xc + (size_t)6 * t;
+    const double* u = xc + (size_t)7 * t;
     const double th = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     const double Om[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
     double Om2[9];
@@ -586,6 +598,9 @@ struct Problem {
   Scal *d_sc = nullptr, *h_sc = nullptr;
   int32_t nblk = 0;
   int grid_chi = 1;
+  DirectPlan dplan;  // exact factorisation of the reduced camera system (empty: PCG fallback)
+  LdlArgs ldl{};
+  bool use_direct = false;
 
   ~Problem() { release(); }
   void release() {
@@ -690,13 +705,50 @@ struct Problem {
     BCHK(up(d_rptr, rptr));
     cam_fixed.resize(NC, 0);
     BCHK(up(d_fixed, cam_fixed));
+    // the reduced camera system's factorisation plan (nested dissection, level schedule: direct.hpp)
+    use_direct = false;
+    dplan = DirectPlan();
+    if (opt.linear_solver != 0) {
+      int64_t max_pairs = 8000000;
+      if (const char* ev = std::getenv("SIM3OPT_BA_MAX_PAIRS")) max_pairs = std::atoll(ev);
+      std::string why;
+      if (sim3opt::build_direct_plan(NC, rptr.data(), bcol.data(), max_pairs, 0, dplan, why, LDL_WG_SUB / 64)) {
+        int32_t *pperm, *pcolptr, *plrow, *plcol, *psrcptr, *psrc, *ppairptr, *ppa, *ppb, *ppcol, *pgptr, *plcolp,
+            *prptr, *pcells;
+        BCHK(up(pperm, dplan.perm)); BCHK(up(pcolptr, dplan.colptr)); BCHK(up(plrow, dplan.lrow));
+        BCHK(up(plcol, dplan.lcol)); BCHK(up(psrcptr, dplan.srcptr)); BCHK(up(psrc, dplan.src));
+        BCHK(up(ppairptr, dplan.pairptr)); BCHK(up(ppa, dplan.pa)); BCHK(up(ppb, dplan.pb));
+        BCHK(up(ppcol, dplan.pcol)); BCHK(up(pgptr, dplan.gptr)); BCHK(up(plcolp, dplan.lcolp));
+        BCHK(up(prptr, dplan.rptr)); BCHK(up(pcells, dplan.cells));
+        ldl.perm = pperm; ldl.colptr = pcolptr; ldl.lrow = plrow; ldl.lcol = plcol; ldl.srcptr = psrcptr;
+        ldl.src = psrc; ldl.pairptr = ppairptr; ldl.pa = ppa; ldl.pb = ppb; ldl.pcol = ppcol; ldl.gptr = pgptr;
+        ldl.lcolp = plcolp; ldl.rptr = prptr; ldl.cells = pcells;
+        ldl.nb = NC;
+        ldl.nL = (int32_t)dplan.nL;
+        BCHK(alloc(ldl.Aperm, 49 * (size_t)dplan.nL)); BCHK(alloc(ldl.bp, 7 * (size_t)NC));
+        BCHK(alloc(ldl.L, 49 * (size_t)dplan.nL)); BCHK(alloc(ldl.Dinv, 49 * (size_t)NC));
+        BCHK(alloc(ldl.y, 7 * (size_t)NC)); BCHK(alloc(ldl.xp, 7 * (size_t)NC));
+        ldl.dbg = nullptr;
+        ldl.lambda = 0.0;  // S carries the damping already
+        use_direct = true;
+        if (opt.verbose)
+          std::fprintf(stderr, "sim3opt ba: exact block Cholesky of the reduced system: %d cameras, %lld blocks in L, "
+                       "%lld block products, tree height %d, %d groups\n", NC, (long long)dplan.nL,
+                       (long long)dplan.npairs, dplan.height, dplan.ngroups());
+      } else if (opt.linear_solver == 1) {
+        err = "linear_solver = 1: " + why;
+        return SIM3OPT_ERR_ARG;
+      } else if (opt.verbose) {
+        std::fprintf(stderr, "sim3opt ba: no exact factorisation (%s): PCG\n", why.c_str());
+      }
+    }
     BCHK(alloc(d_lin, 20 * (size_t)NO)); BCHK(alloc(d_Z, 18 * (size_t)NO));
     BCHK(alloc(d_Hinv, 9 * (size_t)NP)); BCHK(alloc(d_bp, 3 * (size_t)NP)); BCHK(alloc(d_pdmax, NP));
-    BCHK(alloc(d_cdmax, 6 * (size_t)NC));
-    BCHK(alloc(d_S, 36 * (size_t)nblk)); BCHK(alloc(d_g, 6 * (size_t)NC)); BCHK(alloc(d_bc, 6 * (size_t)NC));
-    BCHK(alloc(d_xc, 6 * (size_t)NC)); BCHK(alloc(d_xp, 3 * (size_t)NP));
-    BCHK(alloc(d_r, 6 * (size_t)NC)); BCHK(alloc(d_z, 6 * (size_t)NC)); BCHK(alloc(d_p, 6 * (size_t)NC));
-    BCHK(alloc(d_q, 6 * (size_t)NC)); BCHK(alloc(d_Dinv, 36 * (size_t)NC));
+    BCHK(alloc(d_cdmax, 7 * (size_t)NC));
+    BCHK(alloc(d_S, 49 * (size_t)nblk)); BCHK(alloc(d_g, 7 * (size_t)NC)); BCHK(alloc(d_bc, 7 * (size_t)NC));
+    BCHK(alloc(d_xc, 7 * (size_t)NC)); BCHK(alloc(d_xp, 3 * (size_t)NP));
+    BCHK(alloc(d_r, 7 * (size_t)NC)); BCHK(alloc(d_z, 7 * (size_t)NC)); BCHK(alloc(d_p, 7 * (size_t)NC));
+    BCHK(alloc(d_q, 7 * (size_t)NC)); BCHK(alloc(d_Dinv, 49 * (size_t)NC));
     grid_chi = std::max(1, std::min(1024, (NO + WG - 1) / WG));
     BCHK(alloc(d_pa, 1024)); BCHK(alloc(d_pb, 1024)); BCHK(alloc(d_pc, 1024));
 #undef BCHK
@@ -758,7 +810,7 @@ struct Problem {
                              d_cdmax);
           hipLaunchKernelGGL(k_ba_final, dim3(1), dim3(WG), 0, stream, (const double*)nullptr, 0,
                              (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)d_pdmax, NP,
-                             (const double*)d_cdmax, 6 * NC, d_sc);
+                             (const double*)d_cdmax, 7 * NC, d_sc);
           BA_HIPCHK(hipGetLastError());
           rc = fetch();
           if (rc) return rc;
@@ -768,24 +820,33 @@ struct Problem {
           lambda = opt.user_lambda_init;
           ni = 2.0;
         }
-        BA_HIPCHK(hipMemsetAsync(&d_sc->pcg_fail, 0, sizeof(int32_t), stream));
+        BA_HIPCHK(hipMemsetAsync(&d_sc->pcg_iters, 0, 2 * sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_ba_points, dim3(gp), dim3(WG), 0, stream, NP, d_pptr, d_pobs, d_lin, lambda,
                            d_Hinv, d_bp, d_pdmax);
         hipLaunchKernelGGL(k_ba_obs2, dim3(go), dim3(WG), 0, stream, NO, d_op, d_lin, d_Hinv, d_Z);
         hipLaunchKernelGGL(k_ba_reduced, dim3((nblk + 3) / 4), dim3(WG), 0, stream, nblk, d_brow, d_bcol,
                            d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, d_fixed, lambda, d_S, d_g, d_bc,
                            d_cdmax);
-        hipLaunchKernelGGL(k_ba_pcg, dim3(1), dim3(1024), 0, stream, NC, d_rptr, d_bcol, d_S, d_g, d_xc, d_r,
-                           d_z, d_p, d_q, d_Dinv, opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 20 * NC + 100,
-                           opt.pcg_rel_tol * opt.pcg_rel_tol, d_sc);
+        if (use_direct) {
+          ldl.vals = d_S; ldl.b = d_g; ldl.x = d_xc; ldl.sc = d_sc;
+          hipLaunchKernelGGL(k_ldl_gather, dim3(std::max(1, std::min(1024, (ldl.nL + 3) / 4))), dim3(WG), 0, stream, ldl);
+          const int ng = dplan.ngroups();
+          if (ng > 1) hipLaunchKernelGGL((k_ldl<true, false>), dim3(ng - 1), dim3(LDL_WG_SUB), 0, stream, ldl, 0);
+          hipLaunchKernelGGL((k_ldl<true, true>), dim3(1), dim3(LDL_WG_TOP), 0, stream, ldl, ng - 1);
+          if (ng > 1) hipLaunchKernelGGL((k_ldl<false, true>), dim3(ng - 1), dim3(LDL_WG_SUB), 0, stream, ldl, 0);
+        } else {
+          hipLaunchKernelGGL(k_ba_pcg, dim3(1), dim3(1024), 0, stream, NC, d_rptr, d_bcol, d_S, d_g, d_xc, d_r,
+                             d_z, d_p, d_q, d_Dinv, opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 20 * NC + 100,
+                             opt.pcg_rel_tol * opt.pcg_rel_tol, d_sc);
+        }
         hipLaunchKernelGGL(k_ba_backsub, dim3(gp), dim3(WG), 0, stream, NP, d_pptr, d_pobs, d_oc, d_Hinv,
                            d_bp, d_Z, d_xc, d_xp);
         hipLaunchKernelGGL(k_ba_update, dim3((std::max(NC, 3 * NP) + WG - 1) / WG), dim3(WG), 0, stream, NC, NP,
                            d_xc, d_xp, d_fixed, d_cams, d_pts, (const Scal*)d_sc);
         // scale = x.(lambda x + b) over cameras and points
-        const int gsc = std::max(1, std::min(1024, (6 * NC + WG - 1) / WG));
+        const int gsc = std::max(1, std::min(1024, (7 * NC + WG - 1) / WG));
         const int gsp = std::max(1, std::min(1024, (3 * NP + WG - 1) / WG));
-        hipLaunchKernelGGL(k_ba_scale, dim3(gsc), dim3(WG), 0, stream, 6 * NC, d_xc, d_bc, lambda, d_pb);
+        hipLaunchKernelGGL(k_ba_scale, dim3(gsc), dim3(WG), 0, stream, 7 * NC, d_xc, d_bc, lambda, d_pb);
         hipLaunchKernelGGL(k_ba_scale, dim3(gsp), dim3(WG), 0, stream, 3 * NP, d_xp, d_bp, lambda, d_pc);
         hipLaunchKernelGGL(k_ba_chi2, dim3(grid_chi), dim3(WG), 0, stream, oargs(), d_pa);
         hipLaunchKernelGGL(k_ba_final, dim3(1), dim3(WG), 0, stream, (const double*)d_pa, grid_chi,
@@ -797,8 +858,8 @@ struct Problem {
         T.pcg_iters += h_sc->pcg_iters;
         T.pcg_rel_res = h_sc->pcg_rel;
         double scale = h_sc->scale;
-        tempChi = h_sc->pcg_fail ? DBL_MAX : h_sc->chi2;
-        if (h_sc->pcg_fail) scale = 0.0;
+        tempChi = h_sc->fail ? DBL_MAX : h_sc->chi2;
+        if (h_sc->fail) scale = 0.0;
         rho = (currentChi - tempChi) / (scale + 1e-3);
         if (rho > 0 && std::isfinite(tempChi)) {
           double alpha = 1.0 - std::pow(2 * rho - 1, 3);
@@ -851,6 +912,7 @@ void sim3opt_ba_options_default(sim3opt_ba_options* o) {
   o->max_trials = 10;
   o->pcg_max_iters = 0;
   o->pcg_rel_tol = 1e-12;
+  o->linear_solver = -1;
   o->device = -1;
   o->verbose = 0;
 }
@@ -867,7 +929,8 @@ const char* sim3opt_ba_last_error(const sim3opt_ba* b) { return b ? b->err.c_str
 
 int sim3opt_ba_set_options(sim3opt_ba* b, const sim3opt_ba_options* o) {
   if (!b || !o) return SIM3OPT_ERR_ARG;
-  if (!(o->pixel_noise > 0) || o->max_trials < 1 || !(o->tau > 0) || !(o->pcg_rel_tol >= 0) || o->huber_delta < 0) {
+  if (!(o->pixel_noise > 0) || o->max_trials < 1 || !(o->tau > 0) || !(o->pcg_rel_tol >= 0) || o->huber_delta < 0 ||
+      o->linear_solver < -1 || o->linear_solver > 1) {
     b->err = "ba_set_options: value out of range";
     return SIM3OPT_ERR_ARG;
   }

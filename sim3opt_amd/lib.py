@@ -66,6 +66,7 @@ class BaOptions(C.Structure):
         ("max_trials", C.c_int32),
         ("pcg_max_iters", C.c_int32),
         ("pcg_rel_tol", C.c_double),
+        ("linear_solver", C.c_int32),
         ("device", C.c_int32),
         ("verbose", C.c_int32),
     ]

@@ -172,10 +172,13 @@ def test_gpu_chi2_matches_oracle(huber):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n_cams,n_points", [(0, 12, 400), (7, 30, 1500)])
-def test_gpu_lm_trace_matches_oracle(seed, n_cams, n_points):
+@pytest.mark.parametrize("seed,n_cams,n_points,solver", [(0, 12, 400, 1), (7, 30, 1500, 1), (7, 30, 1500, 0),
+                                                         (3, 60, 2500, -1)])
+def test_gpu_lm_trace_matches_oracle(seed, n_cams, n_points, solver):
+    """solver 1: the reduced camera system by the exact block Cholesky (what ba_demo's LinearSolverEigen
+    does); 0: the block-Jacobi PCG fallback; -1: automatic."""
     P, _ = synthetic_problem(n_cams=n_cams, n_points=n_points, seed=seed)
-    b = gpu_problem(P)
+    b = gpu_problem(P, linear_solver=solver)
     n = b.optimize(6)
     tr = P.optimize(6)
     st = b.stats()
@@ -184,7 +187,7 @@ def test_gpu_lm_trace_matches_oracle(seed, n_cams, n_points):
         assert s["trials"] == t["trials"]
         assert abs(s["chi2_after"] - t["chi2"]) <= 1e-7 * t["chi2"]
         assert abs(s["lambda_"] - t["lam"]) <= 1e-5 * t["lam"]
-        assert s["pcg_rel_res"] < 1e-10
+        assert s["pcg_rel_res"] < 1e-10 and (s["pcg_iters"] > 0) == (solver == 0)
     assert quat_dist(b.cameras()[:, :4], P.cams[:, :4]) < 1e-8
     assert np.abs(b.cameras()[:, 4:] - P.cams[:, 4:]).max() < 1e-7
     assert np.abs(b.points() - P.points).max() < 1e-6
