@@ -16,8 +16,8 @@
 //                 b_p = -sum B^T es, H_pp^-1
 //   k_ba_obs2     thread / observation: Z = (A^T B) H_pp^-1 (6x3)
 //   k_ba_reduced  wavefront / block (i,j) of the reduced camera system: S_ij = [i=j](lambda I + sum
-//                 A^T A) - sum over the listed observation pairs Z_o1 (A^T B)_o2^T; the diagonal block's
-//                 wavefront also forms g_i = b_c,i - sum Z_o b_p(o)
+//                 A^T A) - sum over the listed observation pairs Z_o1 (A^T B)_o2^T (lane = pair, fixed-order
+//                 butterfly sum); the diagonal block's wavefront also forms g_i = b_c,i - sum Z_o b_p(o)
 //   k_ldl*        the reduced camera system S dx_c = g solved exactly: the level-scheduled block
 //                 Cholesky of direct.hpp / direct_kernels.hpp (written for the 7x7 blocks of the
 //                 Sim(3) graphs; the 6x6 camera blocks are stored padded to 7x7 with a unit diagonal
@@ -215,15 +215,15 @@ __global__ __launch_bounds__(WG) void k_ba_obs2(int n_obs, const int32_t* __rest
 
 // reduced camera system: one wavefront per block k = (row i, column j), stored as a 7x7 column-major
 // block (entry (r, c) at r + 7c) whose 6x6 part is S_ij and whose 7th row / column is that of the
-// identity; camera vectors are 7 per camera with a zero pad.  Lane l < 49 = entry l; lanes 49..54
-// build b_c and g of the diagonal block's camera.
+// identity; camera vectors are 7 per camera with a zero pad.  The lanes share out the block's list of
+// observation pairs (lane = pair, 64 at a time, every load independent), each keeping a private 6x6
+// sum; a butterfly over the wavefront adds them in a fixed order.  The diagonal block's list holds
+// every observation of the camera as (o, o): H_cc, b_c and g are formed in the same pass.
 __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __restrict__ brow,
                                                    const int32_t* __restrict__ bcol,
                                                    const int32_t* __restrict__ sptr,
                                                    const int32_t* __restrict__ sa,
                                                    const int32_t* __restrict__ sb,
-                                                   const int32_t* __restrict__ cptr,
-                                                   const int32_t* __restrict__ cobs,
                                                    const int32_t* __restrict__ op,
                                                    const double* __restrict__ lin,
                                                    const double* __restrict__ Z,
@@ -238,54 +238,82 @@ __global__ __launch_bounds__(WG) void k_ba_reduced(int nblk, const int32_t* __re
   const int l49 = lane < 49 ? lane : lane - 49;
   const int r = l49 % 7, c = l49 / 7;
   const bool pad = r == 6 || c == 6;
-  const int r6 = r < 6 ? r : 0, c6 = c < 6 ? c : 0;
+  const bool dg = i == j;
   if (fixed[i] | fixed[j]) {  // setFixed(true): the camera leaves the system (identity row, zero rhs)
-    if (lane < 49) S[(size_t)49 * k + lane] = (i == j && r == c) ? 1.0 : 0.0;
-    if (i == j && lane < 7) {
+    if (lane < 49) S[(size_t)49 * k + lane] = (dg && r == c) ? 1.0 : 0.0;
+    if (dg && lane < 7) {
       g[7 * (size_t)i + lane] = 0.0;
       bc[7 * (size_t)i + lane] = 0.0;
       cdmax[7 * (size_t)i + lane] = 0.0;
     }
     return;
   }
-  double acc = 0.0;
-  for (int e = sptr[k]; e < sptr[k + 1]; ++e) {
-    const double* z = Z + (size_t)18 * sa[e] + 3 * r6;  // Z_o1 row r
-    const double* d = lin + (size_t)20 * sb[e];          // Y_o2 row c = (A^T B) row c
-    const double y0 = d[c6] * d[12] + d[6 + c6] * d[15];
-    const double y1 = d[c6] * d[13] + d[6 + c6] * d[16];
-    const double y2 = d[c6] * d[14] + d[6 + c6] * d[17];
-    acc -= z[0] * y0 + z[1] * y1 + z[2] * y2;
-  }
-  if (i == j) {
-    double hd = 0.0, gb = 0.0, bcv = 0.0;
-    const int comp = lane - 49;  // lanes 49..54
-    const bool rhs = comp >= 0 && comp < 6;
-    const int cm = rhs ? comp : 0;
-    for (int e = cptr[i]; e < cptr[i + 1]; ++e) {
-      const int o = cobs[e];
-      const double* d = lin + (size_t)20 * o;
-      hd += d[r6] * d[c6] + d[6 + r6] * d[6 + c6];
-      if (rhs) {
-        bcv -= d[cm] * d[18] + d[6 + cm] * d[19];
-        const double* z = Z + (size_t)18 * o + 3 * cm;
-        const double* b3 = bp + (size_t)3 * op[o];
-        gb -= z[0] * b3[0] + z[1] * b3[1] + z[2] * b3[2];
+  double acc[36], hd[6], bcv[6], gbv[6];
+#pragma unroll
+  for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) hd[q] = bcv[q] = gbv[q] = 0.0;
+  for (int e = sptr[k] + lane; e < sptr[k + 1]; e += 64) {
+    const int o1 = sa[e], o2 = sb[e];
+    const double* z = Z + (size_t)18 * o1;
+    const double* d = lin + (size_t)20 * o2;
+    double zz[18], dd[20];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) zz[q] = z[q];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) dd[q] = d[q];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {  // Y_o2 row cc = (A^T B) row cc
+      const double y0 = dd[cc] * dd[12] + dd[6 + cc] * dd[15];
+      const double y1 = dd[cc] * dd[13] + dd[6 + cc] * dd[16];
+      const double y2 = dd[cc] * dd[14] + dd[6 + cc] * dd[17];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) acc[6 * rr + cc] -= zz[3 * rr] * y0 + zz[3 * rr + 1] * y1 + zz[3 * rr + 2] * y2;
+    }
+    if (dg && o1 == o2) {
+      const double* b3 = bp + (size_t)3 * op[o1];
+      const double b0 = b3[0], b1 = b3[1], b2 = b3[2];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) acc[6 * rr + cc] += dd[rr] * dd[cc] + dd[6 + rr] * dd[6 + cc];
+        hd[rr] += dd[rr] * dd[rr] + dd[6 + rr] * dd[6 + rr];
+        bcv[rr] -= dd[rr] * dd[18] + dd[6 + rr] * dd[19];
+        gbv[rr] -= zz[3 * rr] * b0 + zz[3 * rr + 1] * b1 + zz[3 * rr + 2] * b2;
       }
     }
-    // undamped diagonal for lambda_0 (computeLambdaInit looks at every vertex's Hessian diagonal)
-    if (lane < 49 && r == c) cdmax[7 * (size_t)i + r] = pad ? 0.0 : hd;
-    acc += hd + (r == c ? lambda : 0.0);
-    if (rhs) {
-      bc[7 * (size_t)i + comp] = bcv;
-      g[7 * (size_t)i + comp] = bcv + gb;
-    }
-    if (comp == 6) {
-      bc[7 * (size_t)i + 6] = 0.0;
-      g[7 * (size_t)i + 6] = 0.0;
-    }
   }
-  if (lane < 49) S[(size_t)49 * k + lane] = pad ? ((i == j && r == c) ? 1.0 : 0.0) : acc;
+  // butterfly sums (every lane ends with the total), then lane = entry picks its value
+  double mine = 0.0, vh = 0.0, vb = 0.0, vg = 0.0;
+  const int idx = pad ? 0 : 6 * r + c;
+#pragma unroll
+  for (int q = 0; q < 36; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    mine = idx == q ? v : mine;
+  }
+  if (dg) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double h = hd[q], b = bcv[q], gg = gbv[q];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        h += __shfl_xor(h, off);
+        b += __shfl_xor(b, off);
+        gg += __shfl_xor(gg, off);
+      }
+      if (lane == q) { vh = h; vb = b; vg = gg; }
+    }
+    if (lane < 7) {
+      // undamped diagonal for lambda_0 (computeLambdaInit looks at every vertex's Hessian diagonal)
+      cdmax[7 * (size_t)i + lane] = lane < 6 ? vh : 0.0;
+      bc[7 * (size_t)i + lane] = lane < 6 ? vb : 0.0;
+      g[7 * (size_t)i + lane] = lane < 6 ? vb + vg : 0.0;
+    }
+    if (r == c) mine += lambda;
+  }
+  if (lane < 49) S[(size_t)49 * k + lane] = pad ? ((dg && r == c) ? 1.0 : 0.0) : mine;
 }
 
 // Fallback: block-Jacobi PCG on S x = g inside ONE workgroup (rows = cameras, padded 7x7 blocks,
@@ -601,6 +629,7 @@ struct Problem {
   DirectPlan dplan;  // exact factorisation of the reduced camera system (empty: PCG fallback)
   LdlArgs ldl{};
   bool use_direct = false;
+  int ldl_wg_sub = LDL_WG_TOP;
 
   ~Problem() { release(); }
   void release() {
@@ -711,8 +740,15 @@ struct Problem {
     if (opt.linear_solver != 0) {
       int64_t max_pairs = 8000000;
       if (const char* ev = std::getenv("SIM3OPT_BA_MAX_PAIRS")) max_pairs = std::atoll(ev);
+      // bottom subtrees of up to a sixth of the cameras, 8 wavefronts each: the reduced system of a
+      // camera chain is a wide band (tracks span several keyframes), its separators are several
+      // columns wide and the top of the tree is expensive -- more of it goes to the parallel groups
+      // than for the pose graphs (profiles/r2_ba_sweep.log)
+      int32_t subtree = std::max(16, NC / 6);
+      if (const char* ev = std::getenv("SIM3OPT_BA_SUBTREE")) subtree = std::atoi(ev);  // tuning knobs
+      if (const char* ev = std::getenv("SIM3OPT_BA_WG_SUB")) ldl_wg_sub = std::max(64, std::min(LDL_WG_TOP, std::atoi(ev) / 64 * 64));
       std::string why;
-      if (sim3opt::build_direct_plan(NC, rptr.data(), bcol.data(), max_pairs, 0, dplan, why, LDL_WG_SUB / 64)) {
+      if (sim3opt::build_direct_plan(NC, rptr.data(), bcol.data(), max_pairs, subtree, dplan, why, ldl_wg_sub / 64)) {
         int32_t *pperm, *pcolptr, *plrow, *plcol, *psrcptr, *psrc, *ppairptr, *ppa, *ppb, *ppcol, *pgptr, *plcolp,
             *prptr, *pcells;
         BCHK(up(pperm, dplan.perm)); BCHK(up(pcolptr, dplan.colptr)); BCHK(up(plrow, dplan.lrow));
@@ -729,6 +765,11 @@ struct Problem {
         BCHK(alloc(ldl.L, 49 * (size_t)dplan.nL)); BCHK(alloc(ldl.Dinv, 49 * (size_t)NC));
         BCHK(alloc(ldl.y, 7 * (size_t)NC)); BCHK(alloc(ldl.xp, 7 * (size_t)NC));
         ldl.dbg = nullptr;
+        if (std::getenv("SIM3OPT_BA_TRACE")) {  // tuning aid: time stamps of the top group's levels / rounds
+          double* p = nullptr;
+          BCHK(alloc(p, 256));
+          ldl.dbg = reinterpret_cast<long long*>(p);
+        }
         ldl.lambda = 0.0;  // S carries the damping already
         use_direct = true;
         if (opt.verbose)
@@ -806,7 +847,7 @@ struct Problem {
                              d_Hinv, d_bp, d_pdmax);
           hipLaunchKernelGGL(k_ba_obs2, dim3(go), dim3(WG), 0, stream, NO, d_op, d_lin, d_Hinv, d_Z);
           hipLaunchKernelGGL(k_ba_reduced, dim3((nblk + 3) / 4), dim3(WG), 0, stream, nblk, d_brow, d_bcol,
-                             d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, d_fixed, 1.0, d_S, d_g, d_bc,
+                             d_sptr, d_sa, d_sb, d_op, d_lin, d_Z, d_bp, d_fixed, 1.0, d_S, d_g, d_bc,
                              d_cdmax);
           hipLaunchKernelGGL(k_ba_final, dim3(1), dim3(WG), 0, stream, (const double*)nullptr, 0,
                              (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)d_pdmax, NP,
@@ -825,15 +866,23 @@ struct Problem {
                            d_Hinv, d_bp, d_pdmax);
         hipLaunchKernelGGL(k_ba_obs2, dim3(go), dim3(WG), 0, stream, NO, d_op, d_lin, d_Hinv, d_Z);
         hipLaunchKernelGGL(k_ba_reduced, dim3((nblk + 3) / 4), dim3(WG), 0, stream, nblk, d_brow, d_bcol,
-                           d_sptr, d_sa, d_sb, d_cptr, d_cobs, d_op, d_lin, d_Z, d_bp, d_fixed, lambda, d_S, d_g, d_bc,
+                           d_sptr, d_sa, d_sb, d_op, d_lin, d_Z, d_bp, d_fixed, lambda, d_S, d_g, d_bc,
                            d_cdmax);
         if (use_direct) {
           ldl.vals = d_S; ldl.b = d_g; ldl.x = d_xc; ldl.sc = d_sc;
           hipLaunchKernelGGL(k_ldl_gather, dim3(std::max(1, std::min(1024, (ldl.nL + 3) / 4))), dim3(WG), 0, stream, ldl);
           const int ng = dplan.ngroups();
-          if (ng > 1) hipLaunchKernelGGL((k_ldl<true, false>), dim3(ng - 1), dim3(LDL_WG_SUB), 0, stream, ldl, 0);
+          if (ng > 1) hipLaunchKernelGGL((k_ldl<true, false>), dim3(ng - 1), dim3(ldl_wg_sub), 0, stream, ldl, 0);
           hipLaunchKernelGGL((k_ldl<true, true>), dim3(1), dim3(LDL_WG_TOP), 0, stream, ldl, ng - 1);
-          if (ng > 1) hipLaunchKernelGGL((k_ldl<false, true>), dim3(ng - 1), dim3(LDL_WG_SUB), 0, stream, ldl, 0);
+          if (ng > 1) hipLaunchKernelGGL((k_ldl<false, true>), dim3(ng - 1), dim3(ldl_wg_sub), 0, stream, ldl, 0);
+          if (ldl.dbg) {
+            long long h[256];
+            BA_HIPCHK(hipStreamSynchronize(stream));
+            BA_HIPCHK(hipMemcpy(h, ldl.dbg, sizeof(h), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "sim3opt ba: top group stamps [us] (level start, after A+B of each round, ..., down start, end):");
+            for (long long i = 0; i < h[255] && i < 255; ++i) std::fprintf(stderr, " %.1f", (h[i] - h[0]) * 0.01);
+            std::fprintf(stderr, "\n");
+          }
         } else {
           hipLaunchKernelGGL(k_ba_pcg, dim3(1), dim3(1024), 0, stream, NC, d_rptr, d_bcol, d_S, d_g, d_xc, d_r,
                              d_z, d_p, d_q, d_Dinv, opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 20 * NC + 100,
