@@ -35,3 +35,16 @@ with open(os.path.join(DST, "gt_kf.txt"), "w") as g:
     for i in sorted(ids):
         g.write(str(i) + " " + gt[i].strip() + "\n")
 print("keyframes", len(ids), "rows kept", n)
+
+# KeyFrame .bin files (read by drawPTAMPoints.cpp:285-332): three single ones for the reader /
+# re-anchoring tests, and the first 45 keyframes of the map (1.07 MB) as a connected piece of the real
+# bundle-adjustment problem ba_demo is run on (tests/test_ba.py)
+KF3 = ["KeyFrame000000.bin", "KeyFrame000011.bin", "KeyFrame000012.bin"]
+os.makedirs(os.path.join(DST, "keyframes"), exist_ok=True)
+for name in KF3:
+    shutil.copyfile(os.path.join(SRC, name), os.path.join(DST, "keyframes", name))
+os.makedirs(os.path.join(DST, "keyframes45"), exist_ok=True)
+first45 = sorted(n for n in os.listdir(SRC) if n.startswith("KeyFrame") and n.endswith(".bin"))[:45]
+for name in first45:
+    shutil.copyfile(os.path.join(SRC, name), os.path.join(DST, "keyframes45", name))
+print("keyframe files:", len(KF3), "+", len(first45))

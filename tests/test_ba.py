@@ -29,10 +29,13 @@ def synthetic_problem(**kw):
     return BO.Problem(d["cams"], d["points"], d["obs_cam"], d["obs_point"], d["obs_uv"]), d
 
 
-def keyframe_problem():
-    """The three fixture keyframes as figureKITTIBA hands them to SaveBALFile
+KF45_DIR = os.path.join(K.FIXTURE, "keyframes45")  # the first 45 keyframes of the reference's KITTI-00 map
+
+
+def keyframe_problem(kf_dir=KF_DIR):
+    """Fixture keyframes as figureKITTIBA hands them to SaveBALFile
     (drawPTAMPoints.cpp:333-371): later keyframes overwrite a point, ids compacted."""
-    frames = [L.read_keyframe_bin(os.path.join(KF_DIR, n)) for n in sorted(os.listdir(KF_DIR))]
+    frames = [L.read_keyframe_bin(os.path.join(kf_dir, n)) for n in sorted(os.listdir(kf_dir))]
     allpts = {}
     for d in frames:
         for pid, p in zip(d["point_ids"], d["points_w"]):
@@ -268,6 +271,34 @@ def test_gpu_kitti_keyframes_ba(tmp_path):
     tcinw = -np.einsum("nji,nj->ni", Rw2c, got[:, 4:])
     assert np.abs(rows[:, 1:4] - tcinw).max() < 1e-12
     assert quat_dist(rows[:, 4:8], got[:, :4] * np.array([-1, -1, -1, 1.0])) < 1e-15
+
+
+@pytest.mark.gpu
+def test_gpu_real_map_piece_45_keyframes(tmp_path):
+    """ba_demo on a connected piece of the reference's real KITTI-00 map: its first 45 keyframes
+    (7 802 points, 20 510 observations, tracks of 1..11+ keyframes, depths down to 5 cm), through the
+    BAL file, 5 iterations (the demo's default).  The restatement solves the full system by sparse LU
+    here, the GPU by Schur complement + block Cholesky."""
+    cams, points, oc, op, uv, R, t = keyframe_problem(KF45_DIR)
+    assert cams.shape[0] == 45 and len(points) == 7802 and len(oc) == 20510
+    path = str(tmp_path / "kf45.bal")
+    L.write_bal(path, R.reshape(-1, 9), t, [718.856, 0, 0], points, oc, op, uv)
+    P = BO.read_bal(path)
+    b = L.BundleAdjuster()
+    b.read_bal(path)
+    c0 = b.chi2()
+    assert abs(c0 - P.chi2()) <= 1e-12 * c0
+    n = b.optimize(5)
+    tr = P.optimize(5)
+    st = b.stats()
+    assert n == len(tr) == 5
+    for s, tt in zip(st, tr):
+        assert s["trials"] == tt["trials"] and abs(s["chi2_after"] - tt["chi2"]) <= 1e-8 * tt["chi2"]
+        assert abs(s["lambda_"] - tt["lam"]) <= 1e-6 * tt["lam"]
+    assert st[-1]["chi2_after"] < 0.25 * c0
+    assert quat_dist(b.cameras()[:, :4], P.cams[:, :4]) < 1e-9
+    assert np.abs(b.cameras()[:, 4:] - P.cams[:, 4:]).max() < 1e-8
+    assert np.abs(b.points() - P.points).max() < 1e-6 * max(1.0, np.abs(P.points).max())
 
 
 @pytest.mark.gpu
