@@ -81,7 +81,9 @@ def cpu_baseline(args, g, gpu_ms_linearize, gpu_value, threads=1):
     G.jacobians(o)
     t_lin = time.perf_counter() - t0
     # the same two phases with every core the box gives this process (OpenMP over edges)
+    # (a one-GPU box of the pool gives a job 16 CPUs although it shows the whole host's 256)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = min(ncores, 16)
     all_cores = None
     if ncores > threads:
         oa = O.default_options(fix_small_angle_b=args.fix_small_angle_b, threads=ncores)
