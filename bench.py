@@ -362,6 +362,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kt = G.kernel_times()
+    ct = G.comm_times() if world > 1 else None  # (before the chi2 below adds its own all-reduce)
     chi2_final = G.chi2()
 
     if rank == 0:
@@ -421,6 +422,13 @@ def main():
             "ms_update_mean": float(np.mean([s.ms_update for s in stats])),
             "roofline": roof,
         }
+        if ct is not None:
+            # rank 0's collectives inside the timed region: device time (includes waiting for the
+            # slowest rank), count, payload -- what the next scaling decision needs
+            npcg = max(sum(int(s.pcg_iters) for s in stats), 1)
+            out["collectives_rank0"] = dict(ct, ms_per_lm_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / K,
+                                            ms_per_pcg_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / npcg,
+                                            fraction_of_step=(ct["ms_allreduce"] + ct["ms_allgather"]) / (dt * 1e3))
         if world == 1 and G.preconditioner_in_use() != 0 and not args.main_only:
             # same K steps with plain block-Jacobi PCG, for comparison (not part of `value`)
             J = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, preconditioner=0,

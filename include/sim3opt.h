@@ -114,6 +114,14 @@ typedef struct sim3opt_kernel_times {
   double ms_update;    int64_t n_update;
 } sim3opt_kernel_times;
 
+/* Device time of the collectives of the row-partitioned path accumulated since initialize / reset
+ * (HIP event pairs on the library's stream around every collective when options.time_kernels is set;
+ * a pair includes the wait for the slowest rank).  bytes: payload of the whole vector / buffer. */
+typedef struct sim3opt_comm_times {
+  double ms_allreduce;  int64_t n_allreduce;  int64_t bytes_allreduce;
+  double ms_allgather;  int64_t n_allgather;  int64_t bytes_allgather;
+} sim3opt_comm_times;
+
 int sim3opt_version(void);
 void sim3opt_options_default(sim3opt_options* o);
 
@@ -170,7 +178,8 @@ int sim3opt_chi2(sim3opt_graph* g, double* chi2);
 int32_t sim3opt_num_iterations(const sim3opt_graph* g);
 int sim3opt_get_stats(const sim3opt_graph* g, int32_t iter, sim3opt_iter_stats* out);
 int sim3opt_get_kernel_times(sim3opt_graph* g, sim3opt_kernel_times* out);
-int sim3opt_reset_kernel_times(sim3opt_graph* g);
+int sim3opt_reset_kernel_times(sim3opt_graph* g);   /* (also clears the collectives' times) */
+int sim3opt_get_comm_times(sim3opt_graph* g, sim3opt_comm_times* out);
 
 /* ---- kernel-level access (parity tests against the CPU oracle, bench roofline) ---- */
 /* per-edge residuals e (m x 7), edge insertion order                EdgeSim3::computeError */

@@ -328,6 +328,12 @@ int sim3opt_get_kernel_times(sim3opt_graph* g, sim3opt_kernel_times* out) {
   return engine_kernel_times(g->engine, out, false);
 }
 
+int sim3opt_get_comm_times(sim3opt_graph* g, sim3opt_comm_times* out) {
+  if (!g || !out) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_times: not initialized");
+  return engine_comm_times(g->engine, out);
+}
+
 int sim3opt_reset_kernel_times(sim3opt_graph* g) {
   if (!g) return SIM3OPT_ERR_ARG;
   if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "kernel_times: not initialized");

@@ -116,7 +116,61 @@ static int ensure_stage(Comm& c, size_t n, std::string& err) {
   return SIM3OPT_OK;
 }
 
+int Comm::stamp(int kind_, bool begin, hipStream_t stream, std::string& err) {
+  if (begin) {
+    if (ev_used + 2 > ev.size()) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      ev.push_back(e0);
+      ev.push_back(e1);
+    }
+    if (ev_kind.size() < ev.size() / 2) ev_kind.resize(ev.size() / 2);
+    ev_kind[ev_used / 2] = kind_;
+    HIPCHK(hipEventRecord(ev[ev_used], stream));
+  } else {
+    HIPCHK(hipEventRecord(ev[ev_used + 1], stream));
+    ev_used += 2;
+  }
+  return SIM3OPT_OK;
+}
+
+// after a stream synchronisation: elapsed times of the recorded pairs into `times`
+int Comm::drain(std::string& err) {
+  for (size_t i = 0; i + 1 < ev_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    if (ev_kind[i / 2] == 0) times.ms_allreduce += ms; else times.ms_allgather += ms;
+  }
+  ev_used = 0;
+  return SIM3OPT_OK;
+}
+
 int Comm::allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err) {
+  if (!active()) return SIM3OPT_OK;
+  if (!timing) return allreduce_impl(dptr, n, op, stream, err);
+  int rc = stamp(0, true, stream, err);
+  if (rc) return rc;
+  rc = allreduce_impl(dptr, n, op, stream, err);
+  if (rc) return rc;
+  times.n_allreduce += 1;
+  times.bytes_allreduce += (int64_t)sizeof(double) * n;
+  return stamp(0, false, stream, err);
+}
+
+int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream, std::string& err) {
+  if (!active()) return SIM3OPT_OK;
+  if (!timing) return allgatherv_impl(dvec, offs, stream, err);
+  int rc = stamp(1, true, stream, err);
+  if (rc) return rc;
+  rc = allgatherv_impl(dvec, offs, stream, err);
+  if (rc) return rc;
+  times.n_allgather += 1;
+  times.bytes_allgather += (int64_t)sizeof(double) * offs[world];
+  return stamp(1, false, stream, err);
+}
+
+int Comm::allreduce_impl(double* dptr, int n, int op, hipStream_t stream, std::string& err) {
   if (!active()) return SIM3OPT_OK;
   if (kind == 1) {
     NCCLCHK(g_api.AllReduce(dptr, dptr, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum,
@@ -136,8 +190,8 @@ int Comm::allreduce(double* dptr, int n, int op, hipStream_t stream, std::string
   return SIM3OPT_OK;
 }
 
-int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
-                     std::string& err) {
+int Comm::allgatherv_impl(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
+                          std::string& err) {
   if (!active()) return SIM3OPT_OK;
   if (kind == 1) {
     // equal spans (the engine's partition; buffers are padded to world x count): ONE in-place
@@ -188,6 +242,10 @@ void Comm::release() {
   if (h_stage) (void)hipHostFree(h_stage);
   h_stage = nullptr;
   h_stage_len = 0;
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  ev.clear();
+  ev_kind.clear();
+  ev_used = 0;
   kind = 0;
   world = 1;
   rank = 0;

@@ -30,6 +30,15 @@ struct Comm {
 
   bool force = false;  // run the collectives even with one rank (transport self-test)
   bool active() const { return world > 1 || force; }
+  // optional timing (sim3opt_options.time_kernels): an event pair around every collective on the
+  // engine's stream, folded into `times` by drain() after the caller's next stream synchronisation.
+  // What a pair measures includes the wait for the slowest peer -- the figure a scaling run needs.
+  bool timing = false;
+  sim3opt_comm_times times{};
+  std::vector<hipEvent_t> ev;     // pool, pairs
+  std::vector<int> ev_kind;       // per pair: 0 all-reduce, 1 all-gather
+  size_t ev_used = 0;
+  int drain(std::string& err);
   // in-place on device memory, ordered on `stream`; op: 0 = sum, 1 = max
   int allreduce(double* dptr, int n, int op, hipStream_t stream, std::string& err);
   // in-place all-gather of a vector split at offs[0..world] (in doubles); rank r contributes
@@ -38,6 +47,11 @@ struct Comm {
   int allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
                  std::string& err);
   void release();
+
+ private:
+  int allreduce_impl(double* dptr, int n, int op, hipStream_t stream, std::string& err);
+  int allgatherv_impl(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream, std::string& err);
+  int stamp(int kind_, bool begin, hipStream_t stream, std::string& err);
 };
 
 // Plan of the in-place all-gather of a vector split at offs[0..world] (in doubles): true when the

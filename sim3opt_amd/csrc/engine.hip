@@ -1309,6 +1309,7 @@ class Engine {
   int fetch_scalars(std::string& err) {
     HIPCHK(hipMemcpyAsync(h_sc, d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    if (comm.timing && comm.ev_used) return comm.drain(err);
     return SIM3OPT_OK;
   }
 
@@ -2292,6 +2293,7 @@ Engine* engine_create(const HostGraph& g, const Structure& s, const sim3opt_opti
     e->comm = *comm;
     *comm = Comm();
   }
+  e->comm.timing = opt.time_kernels != 0;
   status = e->init(g, s, err);
   if (status != SIM3OPT_OK) {
     delete e;
@@ -2311,6 +2313,7 @@ int engine_set_options(Engine* e, const sim3opt_options& opt) {
   const int dev = e->opt.device;
   e->opt = opt;
   e->opt.device = dev;
+  e->comm.timing = opt.time_kernels != 0;
   return SIM3OPT_OK;
 }
 
@@ -2452,7 +2455,21 @@ int engine_linear_solver(const Engine* e) { return e->use_direct ? 1 : 0; }
 
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {
   if (out) *out = e->kt;
-  if (reset) e->kt = sim3opt_kernel_times{};
+  if (reset) {
+    e->kt = sim3opt_kernel_times{};
+    e->comm.times = sim3opt_comm_times{};
+  }
+  return SIM3OPT_OK;
+}
+
+int engine_comm_times(Engine* e, sim3opt_comm_times* out) {
+  std::string err;
+  if (e->comm.ev_used) {  // pairs recorded since the last synchronisation
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return SIM3OPT_ERR_HIP;
+    int rc = e->comm.drain(err);
+    if (rc) return rc;
+  }
+  *out = e->comm.times;
   return SIM3OPT_OK;
 }
 

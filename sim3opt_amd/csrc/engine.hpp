@@ -42,5 +42,6 @@ int engine_bench_stream(Engine* e, int32_t mode, int32_t reps, double* ms_mean, 
 int engine_preconditioner(const Engine* e);
 int engine_linear_solver(const Engine* e);
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset);
+int engine_comm_times(Engine* e, sim3opt_comm_times* out);
 
 }  // namespace sim3opt

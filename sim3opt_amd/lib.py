@@ -82,6 +82,13 @@ class KernelTimes(C.Structure):
     ]
 
 
+class CommTimes(C.Structure):
+    _fields_ = [
+        ("ms_allreduce", C.c_double), ("n_allreduce", C.c_int64), ("bytes_allreduce", C.c_int64),
+        ("ms_allgather", C.c_double), ("n_allgather", C.c_int64), ("bytes_allgather", C.c_int64),
+    ]
+
+
 # every symbol include/sim3opt.h declares, with its signature
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -111,6 +118,7 @@ SYMBOLS = {
     "sim3opt_chi2": (C.c_int, [_vp, _dp]),
     "sim3opt_num_iterations": (C.c_int32, [_vp]),
     "sim3opt_get_stats": (C.c_int, [_vp, C.c_int32, C.POINTER(IterStats)]),
+    "sim3opt_get_comm_times": (C.c_int, [_vp, C.POINTER(CommTimes)]),
     "sim3opt_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes)]),
     "sim3opt_reset_kernel_times": (C.c_int, [_vp]),
     "sim3opt_edge_errors": (C.c_int, [_vp, _dp]),
@@ -385,6 +393,13 @@ class Graph:
         if reset:
             self._chk(self._L.sim3opt_reset_kernel_times(self._g))
         return kt
+
+    def comm_times(self):
+        """Device time, count and payload of the collectives since initialize / the last reset
+        (options.time_kernels): dict of the sim3opt_comm_times fields."""
+        ct = CommTimes()
+        self._chk(self._L.sim3opt_get_comm_times(self._g, C.byref(ct)))
+        return {k: getattr(ct, k) for k, _ in CommTimes._fields_}
 
     # ---- kernel-level access ----
     def edge_errors(self):

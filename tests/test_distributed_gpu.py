@@ -111,12 +111,20 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     uid = np.zeros(128, dtype=np.uint8)
     assert L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) == L.OK
     assert uid.any()
-    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec)
+    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec, time_kernels=1)
     A.add_vertices(g["states"], g["fixed"])
     A.add_edges(g["v0"], g["v1"], g["meas"])
     A.comm_init_rccl(0, 1, uid)
     A.initialize()
     A.optimize(3)
+    # the collectives are timed on the library's stream (bench.py reports them for N > 1)
+    ct = A.comm_times()
+    npcg = sum(s.pcg_iters for s in A.stats())
+    assert ct["n_allreduce"] >= npcg and ct["n_allgather"] >= npcg  # at least one of each per PCG iteration
+    assert ct["ms_allreduce"] > 0 and ct["ms_allgather"] > 0
+    assert ct["bytes_allgather"] >= ct["n_allgather"] * 7 * 8 * (len(g["states"]) - 1)
+    A.kernel_times(reset=True)
+    assert A.comm_times()["n_allreduce"] == 0 and A.comm_times()["ms_allgather"] == 0
     monkeypatch.delenv("SIM3OPT_FORCE_COMM")
     B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec)
     B.add_vertices(g["states"], g["fixed"])
