@@ -220,6 +220,36 @@ def test_gpu_fixed_cameras_keep_their_pose_and_match_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("huber", [2.5, 0.0])
+def test_gpu_ragged_problem_matches_oracle(huber):
+    """Ragged input: a camera without any observation, a point seen once, a point seen twice by the
+    SAME camera (cross terms inside the camera's own block), with and without the robust kernel."""
+    d = BO.synthetic(n_cams=8, n_points=250, seed=13)
+    cams = np.vstack([d["cams"], d["cams"][-1] + [0, 0, 0, 0, 0.5, 0, 1.0]])  # camera 8: no observations
+    pts = np.vstack([d["points"], [[0.3, -0.2, 14.0]]])                        # point seen once
+    k = len(pts) - 1
+    oc = np.concatenate([d["obs_cam"], [2, 3, 3]])
+    op = np.concatenate([d["obs_point"], [k, 5, 5]])                            # point 5: twice by camera 3
+    X = BO.quat_to_R(cams[[2, 3, 3], :4]) @ pts[[k, 5, 5], :, None]
+    X = X[:, :, 0] + cams[[2, 3, 3], 4:]
+    uv_new = np.stack([718.856 * X[:, 0] / X[:, 2] + 607.1928, 718.856 * X[:, 1] / X[:, 2] + 185.2157], axis=1)
+    uv = np.vstack([d["obs_uv"], uv_new + [[0.3, -0.4], [1.0, 0.5], [-0.7, 0.2]]])
+    P = BO.Problem(cams, pts, oc, op, uv, huber=huber)
+    b = gpu_problem(P, huber_delta=huber)
+    assert abs(b.chi2() - P.chi2()) <= 1e-12 * P.chi2()
+    n = b.optimize(5)
+    tr = P.optimize(5)
+    assert n == len(tr)
+    for s, t in zip(b.stats(), tr):
+        assert s["trials"] == t["trials"] and abs(s["chi2_after"] - t["chi2"]) <= 1e-7 * t["chi2"]
+    got = b.cameras()
+    assert quat_dist(got[:, :4], P.cams[:, :4]) < 1e-8 and np.abs(got[:, 4:] - P.cams[:, 4:]).max() < 1e-7
+    # the unobserved camera has a zero gradient: damping alone keeps it where it was
+    assert np.abs(got[8] - cams[8] / np.r_[np.ones(4) * np.linalg.norm(cams[8, :4]), np.ones(3)]).max() < 1e-12
+    assert np.abs(b.points() - P.points).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_gpu_single_step_matches_oracle_solve():
     """One LM trial with lambda given: the Schur-complement step equals the oracle's solve of the
     full system (cameras AND points) to solver precision."""
