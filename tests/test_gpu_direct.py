@@ -261,3 +261,32 @@ def test_kitti_stepwise_reference_run(one, rmse_max, chi_rel):
     if not one:
         gt = np.loadtxt(os.path.join(K.FIXTURE, "gt_kf.txt"), comments="%")[:, [4, 8, 12]]
         assert L.align_trajectory(synth.positions(G.get_vertices()), gt)[1] < 20.0
+
+
+def test_kitti_incremental_closures_reference_arithmetic():
+    """BASELINE.json configs[4] in its own words, reference configuration: the first closures of
+    loopConstraints.txt added one at a time, optimize(100) warm-started after each.  What g2o's rules
+    do with the as-written small-angle coefficient: the first closure runs its 100 iterations, every
+    later one ends after a single iteration (ten rejected trials) -- on the GPU exactly as in the
+    oracle (scripts/gpu_incremental.py runs all 118 and both arithmetics)."""
+    full = K.build_direct_graph(False)
+    nl = 118
+    G = L.Graph()
+    G.add_vertices(full["states"], full["fixed"])
+    G.add_edges(full["v0"][nl:], full["v1"][nl:], full["meas"][nl:])
+    states = full["states"].copy()
+    gi, ci = [], []
+    for k in range(4):
+        G.add_edge(int(full["v0"][k]), int(full["v1"][k]), full["meas"][k])
+        G.initialize()
+        assert G.linear_solver_in_use() == 1
+        gi.append(G.optimize(100))
+        idx = np.r_[np.arange(nl, len(full["v0"])), np.arange(k + 1)]
+        OG = O.Graph(states, full["fixed"], full["v0"][idx], full["v1"][idx], full["meas"][idx])
+        it, tr = OG.optimize(100)
+        states = OG.states.copy()
+        ci.append(it)
+        assert abs(G.stats()[-1].chi2_after - tr[-1].chi2_after) < 2e-3 * tr[-1].chi2_after
+        assert G.stats()[-1].trials == tr[-1].trials
+    assert gi == ci == [100, 1, 1, 1]
+    assert synth.rmse(G.get_vertices(), states) < 1e-3
