@@ -255,6 +255,7 @@ struct LinArgs {
   double delta;
   sim3::Opts opts;
   int32_t dof_mask;  // cleared bit d: Jacobian column d of both endpoints is zero (frozen DoF)
+  DevScalars* sc;    // max |H_dd| starts from zero here (k_diag_reduce, the next launch, raises it)
 };
 
 struct GramTables {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
   const int l = threadIdx.x & 31, es = threadIdx.x >> 5;
   const int ai = blockIdx.x * EPB + es;
   const bool valid = ai < A.n_active;
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.sc->maxdiag_bits = 0ull;  // (instead of a memset: 18 us of host latency)
   int edge = 0;
   if (valid) {
     edge = A.active[ai];
@@ -930,11 +932,18 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
 // VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
 // (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
 // fact; the step is then garbage and must not be applied -- the host rejects the trial)
+// `backup` (may be null) receives the estimates as they were: g2o's push() without a copy of its own.
 __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
                                               const double* __restrict__ x, Sim3* states,
-                                              sim3::Opts opts, const DevScalars* sc) {
+                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup) {
   const int v = blockIdx.x * WG + threadIdx.x;
   if (v >= nv) return;
+  if (backup) {
+    const double* s8 = reinterpret_cast<const double*>(states + v);
+    double* b8 = reinterpret_cast<double*>(backup + v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b8[i] = s8[i];
+  }
   if (sc && sc->fail) return;
   const int h = hidx[v];
   if (h < 0) return;
@@ -947,6 +956,14 @@ __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict_
   d[0] = S.q[0]; d[1] = S.q[1]; d[2] = S.q[2]; d[3] = S.q[3];
   d[4] = S.t[0]; d[5] = S.t[1]; d[6] = S.t[2]; d[7] = S.s;
 }
+
+// pop(): the estimates of a rejected trial go back (a kernel: hipMemcpyAsync costs the host 6-18 us)
+__global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restrict__ src, Sim3* __restrict__ dst) {
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if (i < 8 * nv) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
+}
+
+__global__ void k_reset_fail(DevScalars* sc) { sc->fail = 0; }
 
 // computeScale: sum_j x_j (lambda x_j + b_j)
 __global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
@@ -1111,6 +1128,9 @@ class Engine {
   std::vector<int64_t> offs;
   // timing
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  // phase stamps of the LM loop (linearise | solve | update): recorded without waiting, read after
+  // the trial's one host round trip (the chi2 fetch)
+  hipEvent_t ev_ph[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> pool;  // pairs (start, stop) for per-launch SpMV timing
   size_t pool_used = 0;
   sim3opt_kernel_times kt{};
@@ -1134,6 +1154,7 @@ class Engine {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    for (hipEvent_t& e : ev_ph) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (pcg_graph) (void)hipGraphExecDestroy(pcg_graph);
     if (stream) (void)hipStreamDestroy(stream);
     comm.release();
@@ -1193,6 +1214,7 @@ class Engine {
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ev_a));
     HIPCHK(hipEventCreate(&ev_b));
+    for (hipEvent_t& e : ev_ph) HIPCHK(hipEventCreate(&e));
     HIPCHK(upload(d_states, g.states));
     HIPCHK(hipMalloc((void**)&d_backup, sizeof(Sim3) * (size_t)nv));
     HIPCHK(upload(d_meas, g.meas));
@@ -1795,7 +1817,7 @@ class Engine {
   // (H + lambda I) x = b, exactly; x in d_x.  A non-positive pivot raises d_sc->fail (read by the
   // caller together with the trial's chi2: no extra round trip).
   int direct_solve(double lambda, std::string& err) {
-    HIPCHK(hipMemsetAsync(&d_sc->fail, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_reset_fail, dim3(1), dim3(1), 0, stream, d_sc);
     ldl.vals = d_vals;
     ldl.b = d_b;
     ldl.x = d_x;
@@ -1820,7 +1842,7 @@ class Engine {
   }
 
   // ---- building blocks ----
-  int chi2(double* out, std::string& err) {
+  int chi2(double* out, std::string& err, hipEvent_t before_fetch = nullptr) {
     const int g = grid_for(e_hi - e_lo, WG);
     hipLaunchKernelGGL(k_chi2, dim3(g), dim3(WG), 0, stream, edge_args(), d_part_a);
     hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
@@ -1830,6 +1852,7 @@ class Engine {
       rc = comm.allreduce(&d_sc->chi2, 2, 0, stream, err);
       if (rc) return rc;
     }
+    if (before_fetch) HIPCHK(hipEventRecord(before_fetch, stream));
     rc = fetch_scalars(err);
     if (rc) return rc;
     *out = h_sc->chi2;
@@ -1838,11 +1861,11 @@ class Engine {
   }
 
   int linearize(std::string& err) {
-    HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
     LinArgs A{n_active, d_active, d_ev0, d_ev1, d_meas, d_info, d_kdelta, d_states,
               d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts(),
-              opt.dof_mask};
+              opt.dof_mask, d_sc};
     const int g = (n_active + EPB - 1) / EPB;
+    if (g == 0) HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
     if (g > 0) {
       if (has_info && has_kernel)
         hipLaunchKernelGGL((k_linearize_numeric<true, true>), dim3(g), dim3(WG), 0, stream, A);
@@ -2177,8 +2200,11 @@ class Engine {
     for (int it = 0; it < max_iters && ok; ++it) {
       sim3opt_iter_stats T{};
       double currentChi = 0.0;
-      int rc = timed_begin(err);
-      if (rc) return rc;
+      int rc = SIM3OPT_OK;
+      // phase times: event stamps on the stream, read after the trial's chi2 fetch -- the loop has
+      // ONE host round trip per trial (plus lambda_0's at the first iteration); waiting on every
+      // phase's end event left the GPU idle a quarter of the time on the small graphs
+      HIPCHK(hipEventRecord(ev_ph[0], stream));
       // computeActiveErrors at the start of an iteration: the estimates are those the last trial
       // evaluated (accepted) or restored (rejected), and the evaluation is deterministic, so the
       // value is already here -- one host round trip less per iteration
@@ -2191,9 +2217,7 @@ class Engine {
       T.chi2_before = currentChi;
       rc = linearize(err);
       if (rc) return rc;
-      rc = timed_end(T.ms_linearize, err);
-      if (rc) return rc;
-      kt.ms_linearize += T.ms_linearize;
+      bool lin_pending = true;  // ev_ph[0] -> the first trial's ev_ph[1]
       if (it == 0) {
         rc = fetch_scalars(err);
         if (rc) return rc;
@@ -2204,33 +2228,35 @@ class Engine {
       }
       double rho = 0.0;
       int qmax = 0;
+      auto elapsed = [&](int a, int b, double& acc) -> int {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev_ph[a], ev_ph[b]));
+        acc += ms;
+        return SIM3OPT_OK;
+      };
       do {
-        HIPCHK(hipMemcpyAsync(d_backup, d_states, sizeof(Sim3) * (size_t)nv,
-                              hipMemcpyDeviceToDevice, stream));  // push
-        rc = timed_begin(err);
-        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev_ph[1], stream));  // (push(): k_oplus keeps the old estimates itself)
         int32_t pit = 0;
         double rres = 0.0;
         bool ok2 = true;
         rc = pcg(lambda, &pit, &rres, &ok2, err);
         if (rc) return rc;
-        rc = timed_end(T.ms_solve, err);
-        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev_ph[2], stream));
         T.pcg_iters += pit;
         T.pcg_rel_res = rres;
-        rc = timed_begin(err);
-        if (rc) return rc;
         double scale = 0.0;
         if (ok2) {
           hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
-                             d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr);
+                             d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr, d_backup);
           const int ge = grid_for(7 * (int64_t)(r1 - r0), WG);
           hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
                              lambda, d_part_b);
           hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, ge,
                              &d_sc->scale);
           HIPCHK(hipGetLastError());
-          rc = chi2(&tempChi, err);  // also brings back scale (and the factorisation's verdict)
+          rc = chi2(&tempChi, err, ev_ph[3]);  // also brings back scale (and the factorisation's verdict)
+          if (rc) return rc;
+          rc = elapsed(2, 3, T.ms_update);
           if (rc) return rc;
           scale = h_sc->scale;
           kt.n_update += 1;
@@ -2240,6 +2266,15 @@ class Engine {
           }
         } else {
           tempChi = DBL_MAX;  // solver failed: g2o forces rejection
+          HIPCHK(hipEventSynchronize(ev_ph[2]));
+        }
+        rc = elapsed(1, 2, T.ms_solve);
+        if (rc) return rc;
+        if (lin_pending) {
+          rc = elapsed(0, 1, T.ms_linearize);
+          if (rc) return rc;
+          kt.ms_linearize += T.ms_linearize;
+          lin_pending = false;
         }
         rho = currentChi - tempChi;
         scale += 1e-3;
@@ -2253,11 +2288,10 @@ class Engine {
         } else {
           lambda *= ni;
           ni *= 2.0;
-          HIPCHK(hipMemcpyAsync(d_states, d_backup, sizeof(Sim3) * (size_t)nv,
-                                hipMemcpyDeviceToDevice, stream));  // pop
+          if (ok2)  // pop (a failed solve never touched the estimates -- nor the backup)
+            hipLaunchKernelGGL(k_copy_states, dim3((8 * nv + WG - 1) / WG), dim3(WG), 0, stream, nv,
+                               (const Sim3*)d_backup, d_states);
         }
-        rc = timed_end(T.ms_update, err);
-        if (rc) return rc;
         ++qmax;
       } while (rho < 0 && qmax < opt.max_trials);
       kt.ms_update += T.ms_update;
