@@ -454,6 +454,12 @@ int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* m
   return engine_bench_stream(g->engine, mode, reps, ms_mean, g->err);
 }
 
+int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]) {
+  if (!g || !out || reps < 1) return fail(g, SIM3OPT_ERR_ARG, "bench_spmv_symmetric: bad argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv_symmetric: call sim3opt_initialize first");
+  return engine_bench_spmv_symmetric(g->engine, reps, out, g->err);
+}
+
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin) {
   if (n_block_rows < 0 || !rowptr || world < 1 || !row_begin) return SIM3OPT_ERR_ARG;

@@ -129,6 +129,7 @@ SYMBOLS = {
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    "sim3opt_bench_spmv_symmetric": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_preconditioner_in_use": (C.c_int, [_vp]),
     "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
     "sim3opt_linear_solver_in_use": (C.c_int, [_vp]),
@@ -500,6 +501,13 @@ class Graph:
         ms = C.c_double()
         self._chk(self._L.sim3opt_bench_spmv(self._g, int(reps), C.byref(ms)))
         return ms.value
+
+    def bench_spmv_symmetric(self, reps=20):
+        """Prototype of the two-phase upper-triangle SpMV: (ms phase 1, ms phase 2, max rel difference to
+        the product SpMV, bytes of its stream)."""
+        out = np.zeros(4)
+        self._chk(self._L.sim3opt_bench_spmv_symmetric(self._g, int(reps), _p(out, _dp)))
+        return tuple(float(v) for v in out)
 
     def bench_stream(self, mode, reps=20):
         ms = C.c_double()
