@@ -43,7 +43,8 @@ t_gpu = time.perf_counter() - t0
 out = dict(fix_small_angle_b=FIXB, max_iters_per_closure=MAXIT, closures=nl, gpu_total_seconds=t_gpu,
            gpu_lm_iterations=int(sum(p["iters"] for p in per)),
            gpu_mean_ms_per_closure=float(np.mean([p["ms"] for p in per])),
-           gpu_mean_ms_initialize=float(np.mean([p["ms_initialize"] for p in per])),
+           gpu_median_ms_initialize=float(np.median([p["ms_initialize"] for p in per])),
+           gpu_first_ms_initialize=per[0]["ms_initialize"],
            gpu_final_chi2=per[-1]["chi2"], gpu_exact_solver_closures=int(sum(p["solver"] == 1 for p in per)),
            gpu_rmse_vs_gt_m=L.align_trajectory(synth.positions(G.get_vertices()), gt)[1],
            gpu_first=per[:3], gpu_last=per[-3:])

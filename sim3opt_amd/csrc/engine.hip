@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -34,6 +35,7 @@
 
 #include "amg.hpp"
 #include "comm.hpp"
+#include "devmem.hpp"
 #include "direct.hpp"
 #include "engine.hpp"
 
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(WG) void k_stream_read(const double* __restrict__ s
 template <typename T>
 static hipError_t upload(T*& dptr, const std::vector<T>& h) {
   const size_t bytes = sizeof(T) * std::max<size_t>(h.size(), 1);
-  hipError_t e = hipMalloc((void**)&dptr, bytes);
+  hipError_t e = dev_malloc((void**)&dptr, bytes);
   if (e != hipSuccess) return e;
   if (!h.empty()) e = hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice);
   return e;
@@ -1139,17 +1141,19 @@ class Engine {
   ~Engine() { release(); }
 
   void release() {
+    // cached blocks are handed out again without the device-wide wait a hipFree implies
+    if (stream) (void)hipStreamSynchronize(stream);
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                     d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
                     d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
                     d_sub_first, d_sub_cnt, d_Gm};
     for (void* p : ptrs)
-      if (p) (void)hipFree(p);
+      if (p) dev_free(p);
     for (void* p : amg_owned)
-      if (p) (void)hipFree(p);
+      if (p) dev_free(p);
     amg_owned.clear();
     for (void* p : direct_owned)
-      if (p) (void)hipFree(p);
+      if (p) dev_free(p);
     direct_owned.clear();
     if (h_sc) (void)hipHostFree(h_sc);
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
@@ -1212,12 +1216,15 @@ class Engine {
     n_active = (int32_t)l_active.size();
     has_info = g.has_info;
     has_kernel = g.has_kernel;
+    const bool itrace = std::getenv("SIM3OPT_INIT_TRACE") != nullptr;
+    auto inow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double it0 = inow();
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ev_a));
     HIPCHK(hipEventCreate(&ev_b));
     for (hipEvent_t& e : ev_ph) HIPCHK(hipEventCreate(&e));
     HIPCHK(upload(d_states, g.states));
-    HIPCHK(hipMalloc((void**)&d_backup, sizeof(Sim3) * (size_t)nv));
+    HIPCHK(dev_malloc((void**)&d_backup, sizeof(Sim3) * (size_t)nv));
     HIPCHK(upload(d_meas, g.meas));
     HIPCHK(upload(d_ev0, g.ev0));
     HIPCHK(upload(d_ev1, g.ev1));
@@ -1249,11 +1256,11 @@ class Engine {
     HIPCHK(upload(d_slot10, l_s10));
     HIPCHK(upload(d_inc0, l_i0));
     HIPCHK(upload(d_inc1, l_i1));
-    HIPCHK(hipMalloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
+    HIPCHK(dev_malloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
     HIPCHK(hipMemset(d_vals, 0, sizeof(double) * 49 * (size_t)nnzb));
     const size_t ninc = (size_t)s.incptr[nb];
-    HIPCHK(hipMalloc((void**)&d_scratch, sizeof(double) * 35 * std::max<size_t>(ninc, 1)));
-    HIPCHK(hipMalloc((void**)&d_Minv, sizeof(double) * 49 * (size_t)nb));
+    HIPCHK(dev_malloc((void**)&d_scratch, sizeof(double) * 35 * std::max<size_t>(ninc, 1)));
+    HIPCHK(dev_malloc((void**)&d_Minv, sizeof(double) * 49 * (size_t)nb));
     // preconditioner choice: chain segments for chain-like graphs (few blocks per row)
     // automatic: chain segments only when almost every edge is a chain link (KITTI with one loop:
     // 3963 PCG iterations per 30 LM iterations instead of 621642); with many loops the low-rank
@@ -1272,10 +1279,12 @@ class Engine {
     // converges in tens of iterations); graphs too small for a hierarchy (<= 256 rows) get chain
     // segments if they are nearly pure chains; block-Jacobi otherwise.
     // (naming a preconditioner asks for the PCG)
+    const double it1 = inow();
     if (opt.linear_solver == 1 || (opt.linear_solver < 0 && opt.preconditioner < 0)) {
       int rc = direct_init(s, err);
       if (rc) return rc;
     }
+    const double it2 = inow();
     if (!use_direct &&
         (opt.preconditioner == 2 || (opt.preconditioner < 0 && opt.fix_small_angle_b != 0))) {
       int rc = amg_init(s, opt.preconditioner < 0, err);
@@ -1296,7 +1305,7 @@ class Engine {
           }
       HIPCHK(upload(d_sub_first, sf));
       HIPCHK(upload(d_sub_cnt, scnt));
-      HIPCHK(hipMalloc((void**)&d_Gm, sizeof(double) * 49 * (size_t)nb));
+      HIPCHK(dev_malloc((void**)&d_Gm, sizeof(double) * 49 * (size_t)nb));
     }
     double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q, &d_s};
     for (double** v : vecs) {
@@ -1304,16 +1313,16 @@ class Engine {
       int64_t padded = 0;
       (void)allgather_equal_plan(offs.data(), comm.world, nullptr, &padded);
       const size_t n_alloc = std::max<size_t>((size_t)n, (size_t)padded);
-      HIPCHK(hipMalloc((void**)v, sizeof(double) * n_alloc));
+      HIPCHK(dev_malloc((void**)v, sizeof(double) * n_alloc));
       HIPCHK(hipMemset(*v, 0, sizeof(double) * n_alloc));
     }
     if (use_amg) {  // level 0 aliases the system's own arrays and vectors
       int rc = amg_bind(s, err);
       if (rc) return rc;
     }
-    HIPCHK(hipMalloc((void**)&d_part_a, sizeof(double) * SPAN_GRID_MAX));
-    HIPCHK(hipMalloc((void**)&d_part_b, sizeof(double) * SPAN_GRID_MAX));
-    HIPCHK(hipMalloc((void**)&d_sc, sizeof(DevScalars)));
+    HIPCHK(dev_malloc((void**)&d_part_a, sizeof(double) * SPAN_GRID_MAX));
+    HIPCHK(dev_malloc((void**)&d_part_b, sizeof(double) * SPAN_GRID_MAX));
+    HIPCHK(dev_malloc((void**)&d_sc, sizeof(DevScalars)));
     HIPCHK(hipMemset(d_sc, 0, sizeof(DevScalars)));
     HIPCHK(hipHostMalloc((void**)&h_sc, sizeof(DevScalars)));
     // Gram task tables
@@ -1326,6 +1335,9 @@ class Engine {
       for (int r = 0; r <= c; ++r) { tab.tr[t] = (unsigned char)r; tab.tc[t] = (unsigned char)c; ++t; }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tab, sizeof(tab)));
     HIPCHK(hipDeviceSynchronize());
+    if (itrace)
+      std::fprintf(stderr, "sim3opt engine init: uploads %.2f ms, factorisation plan + its uploads %.2f ms, rest %.2f ms\n",
+                   it1 - it0, it2 - it1, inow() - it2);
     return SIM3OPT_OK;
   }
 
@@ -1385,13 +1397,13 @@ class Engine {
   // ---- aggregation multigrid ----
   template <typename T>
   int amg_up(T*& dptr, const std::vector<T>& h, std::string& err) {
-    HIPCHK(hipMalloc((void**)&dptr, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    HIPCHK(dev_malloc((void**)&dptr, sizeof(T) * std::max<size_t>(h.size(), 1)));
     amg_owned.push_back(dptr);
     if (!h.empty()) HIPCHK(hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return SIM3OPT_OK;
   }
   int amg_alloc(double*& dptr, size_t count, std::string& err) {
-    HIPCHK(hipMalloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
+    HIPCHK(dev_malloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
     amg_owned.push_back(dptr);
     HIPCHK(hipMemset(dptr, 0, sizeof(double) * std::max<size_t>(count, 1)));
     return SIM3OPT_OK;
@@ -1492,7 +1504,7 @@ class Engine {
       }
       if (amg_fp32) {
         const size_t n32 = (size_t)98 * (size_t)((std::max<int64_t>(L.nnzb, 1) + 1) / 2);  // whole pairs
-        HIPCHK(hipMalloc((void**)&L.vals32, sizeof(float) * n32));
+        HIPCHK(dev_malloc((void**)&L.vals32, sizeof(float) * n32));
         HIPCHK(hipMemset(L.vals32, 0, sizeof(float) * n32));
         amg_owned.push_back(L.vals32);
       }
@@ -1732,14 +1744,14 @@ class Engine {
   template <typename T>
   int direct_up(const T*& dptr, const std::vector<T>& h, std::string& err) {
     T* p = nullptr;
-    HIPCHK(hipMalloc((void**)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    HIPCHK(dev_malloc((void**)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
     direct_owned.push_back(p);
     if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     dptr = p;
     return SIM3OPT_OK;
   }
   int direct_alloc(double*& dptr, size_t count, std::string& err) {
-    HIPCHK(hipMalloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
+    HIPCHK(dev_malloc((void**)&dptr, sizeof(double) * std::max<size_t>(count, 1)));
     direct_owned.push_back(dptr);
     HIPCHK(hipMemset(dptr, 0, sizeof(double) * std::max<size_t>(count, 1)));
     return SIM3OPT_OK;
@@ -2375,7 +2387,7 @@ int engine_set_states(Engine* e, const Sim3* in, std::string& err) {
 
 int engine_edge_errors(Engine* e, double* out, std::string& err) {
   double* d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_out, sizeof(double) * 7 * std::max<size_t>((size_t)e->ne, 1)));
+  HIPCHK(dev_malloc((void**)&d_out, sizeof(double) * 7 * std::max<size_t>((size_t)e->ne, 1)));
   EdgeArgs ea = e->edge_args();
   ea.e_lo = 0;
   ea.e_hi = e->ne;
@@ -2384,7 +2396,7 @@ int engine_edge_errors(Engine* e, double* out, std::string& err) {
   if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
   if (le == hipSuccess)
     le = hipMemcpy(out, d_out, sizeof(double) * 7 * (size_t)e->ne, hipMemcpyDeviceToHost);
-  (void)hipFree(d_out);
+  dev_free(d_out);
   if (le != hipSuccess) {
     err = std::string("edge_errors: ") + hipGetErrorString(le);
     return SIM3OPT_ERR_HIP;
@@ -2517,19 +2529,19 @@ int engine_bench_spmv_symmetric(Engine* e, int32_t reps, double out[4], std::str
   int32_t *d_ur = nullptr, *d_uc = nullptr, *d_us = nullptr, *d_lp = nullptr, *d_li = nullptr;
   double *d_uv = nullptr, *d_t = nullptr, *d_y = nullptr;
   std::vector<void*> tmp;
-  auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+  auto cleanup = [&]() { for (void* p : tmp) dev_free(p); };
 #define SYM_UP(D, H)                                                                              \
   do {                                                                                            \
-    if (hipMalloc((void**)&D, sizeof(int32_t) * std::max<size_t>(H.size(), 1)) != hipSuccess) {    \
+    if (dev_malloc((void**)&D, sizeof(int32_t) * std::max<size_t>(H.size(), 1)) != hipSuccess) {    \
       cleanup(); err = "bench_spmv_symmetric: hipMalloc"; return SIM3OPT_ERR_HIP; }               \
     tmp.push_back(D);                                                                             \
     (void)hipMemcpy(D, H.data(), sizeof(int32_t) * H.size(), hipMemcpyHostToDevice);               \
   } while (0)
   SYM_UP(d_ur, urowptr); SYM_UP(d_uc, ucol); SYM_UP(d_us, usrc); SYM_UP(d_lp, lptr); SYM_UP(d_li, lidx);
 #undef SYM_UP
-  if (hipMalloc((void**)&d_uv, sizeof(double) * 49 * (size_t)nU) != hipSuccess ||
-      hipMalloc((void**)&d_t, sizeof(double) * 7 * (size_t)nU) != hipSuccess ||
-      hipMalloc((void**)&d_y, sizeof(double) * 7 * (size_t)nb) != hipSuccess) {
+  if (dev_malloc((void**)&d_uv, sizeof(double) * 49 * (size_t)nU) != hipSuccess ||
+      dev_malloc((void**)&d_t, sizeof(double) * 7 * (size_t)nU) != hipSuccess ||
+      dev_malloc((void**)&d_y, sizeof(double) * 7 * (size_t)nb) != hipSuccess) {
     if (d_uv) tmp.push_back(d_uv);
     if (d_t) tmp.push_back(d_t);
     cleanup();
