@@ -47,8 +47,8 @@ out = dict(fix_small_angle_b=FIXB, max_iters_per_closure=MAXIT, closures=nl, gpu
            gpu_first_ms_initialize=per[0]["ms_initialize"],
            gpu_final_chi2=per[-1]["chi2"], gpu_exact_solver_closures=int(sum(p["solver"] == 1 for p in per)),
            gpu_rmse_vs_gt_m=L.align_trajectory(synth.positions(G.get_vertices()), gt)[1],
-           gpu_first=per[:3], gpu_last=per[-3:])
-print(json.dumps({k: v for k, v in out.items() if not k.endswith(("first", "last"))}), flush=True)
+           gpu_iters_per_closure=[p["iters"] for p in per], gpu_first=per[:3], gpu_last=per[-3:])
+print(json.dumps({k: v for k, v in out.items() if not k.endswith(("first", "last", "per_closure"))}), flush=True)
 if "--no-cpu" not in sys.argv:
     from oracle import oracle as O  # checker / baseline only
     states = full["states"].copy()
@@ -69,7 +69,7 @@ if "--no-cpu" not in sys.argv:
                cpu_rmse_vs_gt_m=L.align_trajectory(synth.positions(states), gt)[1],
                rmse_gpu_vs_cpu_m=synth.rmse(G.get_vertices(), states), speedup=t_cpu / t_gpu,
                closures_with_equal_iteration_count=int(sum(a["iters"] == b["iters"] for a, b in zip(per, cper))),
-               cpu_first=cper[:3], cpu_last=cper[-3:])
+               cpu_iters_per_closure=[p["iters"] for p in cper], cpu_first=cper[:3], cpu_last=cper[-3:])
     print(json.dumps({k: v for k, v in out.items() if k.startswith(("cpu_", "rmse", "speed", "closures_w")) and not k.endswith(("first", "last"))}), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r2_incremental_fixb%d.json" % FIXB), "w"), indent=1)
