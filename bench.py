@@ -296,12 +296,12 @@ def main():
         if args.transport == "rccl":
             # the library builds its own RCCL communicator from an id broadcast over torch's group
             uid = np.zeros(128, dtype=np.uint8)
-            ok = 1
             if rank == 0 and L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) != L.OK:
-                ok = 0
+                uid[:] = 0  # (an all-zero id tells every rank that rank 0 has none: nobody may block in init)
             t = torch.from_numpy(uid).cuda()
             dist.broadcast(t, 0)
             uid = np.ascontiguousarray(t.cpu().numpy())
+            ok = 1 if uid.any() else 0
             if ok and L.load().sim3opt_comm_init(G._g, rank, world,
                                                  uid.ctypes.data_as(L._up)) != L.OK:
                 sys.stderr.write("sim3opt_comm_init: " + L.load().sim3opt_last_error(G._g).decode() + "\n")
