@@ -26,4 +26,4 @@ for pre in (-1, 0):
     out["preconditioner=%d" % pre] = rec
     print(json.dumps(rec), flush=True)
     G.close()
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r1_cfg3_optimize100.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r2_cfg3_optimize100.json"), "w"), indent=1)
