@@ -71,36 +71,61 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
   const int r = l49 % 7, c = l49 / 7;
   double acc = 0.0;
   const int e0 = gptr[cb], e1 = gptr[cb + 1];
-  for (int e = e0; e < e1; e += 4) {
-    const int m = e1 - e < 4 ? e1 - e : 4;
-    int kk[4];
-    double av[4], piv[4], pjv[4];
+  if (HASP) {
+    // The operands of the two products that exist in memory -- column c of P_j, column r of P_i --
+    // are loaded in the layout the lane needs them in (seven consecutive doubles each, from lines
+    // the cache holds); only A and T = A P_j go through the LDS crossbar.  With all four operands
+    // shuffled the kernel was bound by that crossbar (56 ds_bpermute per fine block); the texture
+    // path was idle.  Same products in the same order: bit-identical results.
+    constexpr int GF = 1;
+    for (int e = e0; e < e1; e += GF) {
+      const int m = e1 - e < GF ? e1 - e : GF;
+      int kk[GF];
+      double av[GF], pj[GF][7], pi[GF][7];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (u < m) {
-        kk[u] = gblk[e + u];
-        av[u] = vals_f[(size_t)49 * kk[u] + l49];
-        if (HASP) {
-          piv[u] = P[(size_t)49 * grow[e + u] + l49];
-          pjv[u] = P[(size_t)49 * colidx_f[kk[u]] + l49];
+      for (int u = 0; u < GF; ++u)
+        if (u < m) {
+          kk[u] = gblk[e + u];
+          av[u] = vals_f[(size_t)49 * kk[u] + l49];
+          const double* pjp = P + (size_t)49 * colidx_f[kk[u]] + 7 * c;
+          const double* pip = P + (size_t)49 * grow[e + u] + 7 * r;
+#pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            pj[u][q] = pjp[q];
+            pi[u][q] = pip[q];
+          }
         }
-      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (u < m) {
-        if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
-        if (HASP) {
+      for (int u = 0; u < GF; ++u)
+        if (u < m) {
+          if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
           double t = 0.0;  // T = A P_j
 #pragma unroll
-          for (int q = 0; q < 7; ++q) t += __shfl(av[u], r + 7 * q) * __shfl(pjv[u], q + 7 * c);
+          for (int q = 0; q < 7; ++q) t += __shfl(av[u], r + 7 * q) * pj[u][q];
           double o = 0.0;  // P_i^T T
 #pragma unroll
-          for (int q = 0; q < 7; ++q) o += __shfl(piv[u], q + 7 * r) * __shfl(t, q + 7 * c);
+          for (int q = 0; q < 7; ++q) o += pi[u][q] * __shfl(t, q + 7 * c);
           acc += o;
-        } else {
+        }
+    }
+  } else {
+    for (int e = e0; e < e1; e += 4) {
+      const int m = e1 - e < 4 ? e1 - e : 4;
+      int kk[4];
+      double av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+          kk[u] = gblk[e + u];
+          av[u] = vals_f[(size_t)49 * kk[u] + l49];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+          if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
           acc += av[u];
         }
-      }
+    }
   }
   if (lane < 49) vals_c[(size_t)49 * cb + lane] = acc;
 }
