@@ -252,20 +252,25 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
             if (kbase + lane < kb) { ia = A.pa[kbase + lane]; ib = A.pb[kbase + lane]; ic = A.pcol[kbase + lane]; }
           }
           const int off = k - kbase;
-          int m = kb - k < 8 ? kb - k : 8;
+          constexpr int PBATCH = 2;  // products in flight (3 and more spill: the kernel sits at 227 VGPRs)
+          int m = kb - k < PBATCH ? kb - k : PBATCH;
           if (64 - off < m) m = 64 - off;
-          double av[8], bv[8], yv[8];
+          // L(i,k) arrives in the lane's own layout and is shuffled; row c of L(j,k) -- the other
+          // operand of entry (r, c) -- is read straight from memory (seven strided loads from lines
+          // that one load of the block would fetch anyway): half the LDS-crossbar traffic
+          double av[PBATCH], bm[PBATCH][7], yv[PBATCH];
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < PBATCH; ++i)
             if (i < m) {
               const int s_a = __builtin_amdgcn_readlane(ia, off + i);
               const int s_b = __builtin_amdgcn_readlane(ib, off + i);
               av[i] = A.L[(size_t)49 * s_a + l49];
-              bv[i] = A.L[(size_t)49 * s_b + l49];
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) bm[i][mm] = A.L[(size_t)49 * s_b + c + 7 * mm];
               yv[i] = A.y[(size_t)7 * __builtin_amdgcn_readlane(ic, off + i) + c];
             }
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < PBATCH; ++i)
             if (i < m) {
               while (k + i == kend) {  // (a block boundary inside the batch)
                 end_slot();
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
                 begin_slot();  // t < n: product k + i belongs to a block of this cell
               }
 #pragma unroll
-              for (int mm = 0; mm < 7; ++mm) acc -= __shfl(av[i], 7 * mm + r) * __shfl(bv[i], 7 * mm + c);
+              for (int mm = 0; mm < 7; ++mm) acc -= __shfl(av[i], 7 * mm + r) * bm[i][mm];
               tacc += av[i] * yv[i];  // (used by diagonal blocks only)
             }
           k += m;
