@@ -983,6 +983,8 @@ int sim3opt_ba_set_options(sim3opt_ba* b, const sim3opt_ba_options* o) {
     b->err = "ba_set_options: value out of range";
     return SIM3OPT_ERR_ARG;
   }
+  if (b->ready && (o->linear_solver != b->opt.linear_solver || o->device != b->opt.device))
+    b->release();  // the factorisation plan / the device are chosen at the next upload
   b->opt = *o;
   return SIM3OPT_OK;
 }
@@ -1003,6 +1005,10 @@ int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, 
     }
   for (size_t i = 0; i < 7 * (size_t)n_cams; ++i)
     if (!std::isfinite(cam_qt[i])) { b->err = "ba_set_problem: non-finite camera"; return SIM3OPT_ERR_ARG; }
+  for (size_t i = 0; i < 3 * (size_t)n_points; ++i)
+    if (!std::isfinite(points[i])) { b->err = "ba_set_problem: non-finite point"; return SIM3OPT_ERR_ARG; }
+  for (size_t i = 0; i < 2 * (size_t)n_obs; ++i)
+    if (!std::isfinite(obs_uv[i])) { b->err = "ba_set_problem: non-finite observation"; return SIM3OPT_ERR_ARG; }
   b->release();
   b->cams.resize(n_cams);
   for (int32_t c = 0; c < n_cams; ++c) {

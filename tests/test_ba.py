@@ -145,6 +145,10 @@ def test_ba_argument_checks():
         b.set_problem(cams, pts, [0, 1], [0, 5], [[1, 1], [2, 2]])
     with pytest.raises(ValueError):
         b.set_problem(cams, pts, [0, 1], [0], [[1, 1], [2, 2]])
+    with pytest.raises(L.Sim3OptError):  # non-finite input
+        b.set_problem(cams, [[0, 0, np.nan], [1, 0, 6.0]], [0, 1], [0, 1], [[1, 1], [2, 2]])
+    with pytest.raises(L.Sim3OptError):
+        b.set_problem(cams, pts, [0, 1], [0, 1], [[1, np.inf], [2, 2]])
     with pytest.raises(L.Sim3OptError):
         b.set_options(pixel_noise=0.0)
     with pytest.raises(AttributeError):
