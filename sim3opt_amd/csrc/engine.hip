@@ -510,7 +510,9 @@ __global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restric
 // the bytes; vectors, accumulation and the smoother inverses stay FP64) -- the PCG's own SpMV
 // (MODE 0) always reads the FP64 blocks.
 template <int CH, bool NT, int MODE, typename VT = double>
-__global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
+__global__ __launch_bounds__(WG)
+// (the FP32 smoothing pass also carries the r.z partial now: keep it at 6 wavefronts per SIMD, 80 VGPRs)
+__attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
                                                   const VT* __restrict__ vals,
@@ -524,6 +526,11 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
                                                   const int32_t* __restrict__ agg,
                                                   double xc_scale) {
   __shared__ double sh[4];
+  __shared__ int sh_cnt;
+  if (MODE == 2) {  // (arrival counter of the barrier-free partial sum below)
+    if (threadIdx.x == 0) sh_cnt = 0;
+    __syncthreads();
+  }
   if (sc) {
     if (sc->done) return;
     if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
@@ -574,7 +581,13 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
         double o = pr_;
 #pragma unroll
         for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
-        if (lane < 7) q[(size_t)7 * row + lane] = pi + o;
+        if (lane < 7) {
+          const double zo = pi + o;
+          q[(size_t)7 * row + lane] = zo;
+          // the PCG's r.z where z is born (level 0's last pass writes z = M^-1 r and holds r): the
+          // SpMV that follows then needs no load of r -- 11 us of its 166 (measured)
+          if (MODE == 2 && partials) pr += rv_n * zo;
+        }
       }
     }
   };
@@ -663,6 +676,20 @@ __global__ __launch_bounds__(WG) void k_spmv_span(int nb, const int32_t* __restr
       xgc = xgn;
     }
     row_end(row, acc);  // last row of the span
+  }
+  if (MODE == 2 && partials) {
+    // no barrier at the end of a streaming kernel: every wavefront leaves its sum in LDS and goes;
+    // the one that arrives last adds the four in index order (deterministic) and writes the partial
+    const double t = wave_sum(pr);
+    if (lane == 0) {
+      sh[threadIdx.x >> 6] = t;
+      __threadfence_block();
+      if (atomicAdd(&sh_cnt, 1) == 3) {
+        __threadfence_block();
+        partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+      }
+    }
+    return;
   }
   if (MODE != 0) return;
   const double s = block_sum(pq, sh);
@@ -1623,15 +1650,18 @@ class Engine {
     // have it inside their diagonal blocks.  Level 0 streams once (non-temporal), the rest is small.
     // Only level-0 launches test the `done` flag: on the latency-bound coarse levels that dependent
     // scalar load in front of the kernel costs more than the few idle launches after convergence.
+    // level 0's smoothing pass is the cycle's last kernel: it writes z = M^-1 r and leaves the partials
+    // of r.z for the PCG (multiplicative cycle only)
+    double* const rz_part = level == 0 && mode == 2 && !amg_additive ? d_part_b : nullptr;
 #define AMG_SPMV(NTV, MODEV)                                                                     \
   hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
-                     L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, (double*)nullptr, rvec,     \
+                     L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, rz_part, rvec,              \
                      const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
                      (const int32_t*)L.agg, amg_over)
 #define AMG_SPMV32(NTV, MODEV)                                                                    \
   hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
                      L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0,         \
-                     (double*)nullptr, rvec, const_cast<double*>(xc),                               \
+                     rz_part, rvec, const_cast<double*>(xc),                                        \
                      level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over)
     if (amg_fp32) {
       if (level == 0) { if (mode == 1) AMG_SPMV32(true, 1); else AMG_SPMV32(true, 2); }
@@ -1940,13 +1970,13 @@ class Engine {
 #undef SPAN_CASE
   }
 
-  int spmv_launch(double lambda, const double* z, std::string& err) {  // the PCG's SpMV: w = A z, w.z, r.z
+  int spmv_launch(double lambda, const double* z, const double* rv, std::string& err) {  // the PCG's SpMV: w = A z, w.z (and r.z)
     hipEvent_t a = nullptr, b = nullptr;
     if (opt.time_kernels) {
       int rc = pool_get(a, b, err);
       if (rc) return rc;
     }
-    spmv_raw(lambda, z, d_q, d_r, d_sc, a, b);
+    spmv_raw(lambda, z, d_q, rv, d_sc, a, b);
     return SIM3OPT_OK;
   }
 
@@ -2003,6 +2033,9 @@ class Engine {
                   bool* chain_broke, std::string& err) {
     const bool use_chain = prec == 1, use_mg = prec == 2;
     double* const zin = use_mg ? d_az : d_z;  // preconditioned residual the PCG consumes
+    // r.z: from the SpMV's own pass over r -- or, with the multiplicative multigrid cycle, from the
+    // cycle's last kernel, which holds r and writes z (the SpMV then skips its load of r)
+    const double* const spmv_r = use_mg && !amg_additive ? nullptr : d_r;
     const int nloc = r1 - r0;
     const int gj = std::max(1, (nloc + WG - 1) / WG);
     const int gv = grid_for((nloc + 8) / 9, 4);  // 36 block rows per workgroup pass
@@ -2094,7 +2127,7 @@ class Engine {
       hipGraph_t gr = nullptr;
       HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       for (int c = 0; c < graph_iters; ++c) {
-        spmv_raw(lambda, zin, d_q, d_r, d_sc);
+        spmv_raw(lambda, zin, d_q, spmv_r, d_sc);
         if (pre_sum)
           hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
                              &d_sc->tmp_pq);
@@ -2139,7 +2172,7 @@ class Engine {
       }
       const int todo = graphed && it == 0 ? 1 : std::min(chunk, max_it - it);
       for (int c = 0; c < todo; ++c) {
-        rc = spmv_launch(lambda, zin, err);
+        rc = spmv_launch(lambda, zin, spmv_r, err);
         if (rc) return rc;
         if (pre_sum)  // [w.z, r.z] -> tmp_pq, tmp_rz (adjacent)
           hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, d_part_a, d_part_b, gs,
