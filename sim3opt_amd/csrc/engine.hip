@@ -526,8 +526,9 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
                                                   const int32_t* __restrict__ agg,
                                                   double xc_scale) {
   __shared__ double sh[4];
+  __shared__ double sh2[4];
   __shared__ int sh_cnt;
-  if (MODE == 2) {  // (arrival counter of the barrier-free partial sum below)
+  if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
     if (threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
   }
@@ -692,11 +693,19 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
     return;
   }
   if (MODE != 0) return;
-  const double s = block_sum(pq, sh);
-  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s;
-  if (rvec) {
-    const double t = block_sum(pr, sh);
-    if (threadIdx.x == 0) partials_r[blockIdx.x] = t;
+  {  // the same barrier-free partial sums (w.z, and r.z when this pass reads r)
+    const double s = wave_sum(pq);
+    const double t = rvec ? wave_sum(pr) : 0.0;
+    if (lane == 0) {
+      sh[threadIdx.x >> 6] = s;
+      sh2[threadIdx.x >> 6] = t;
+      __threadfence_block();
+      if (atomicAdd(&sh_cnt, 1) == 3) {
+        __threadfence_block();
+        if (partials) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (rvec) partials_r[blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+      }
+    }
   }
 }
 
