@@ -2299,6 +2299,8 @@ class Engine {
         HIPCHK(hipEventRecord(ev_ph[2], stream));
         T.pcg_iters += pit;
         T.pcg_rel_res = rres;
+        if (opt.verbose >= 2)
+          std::fprintf(stderr, "  trial %d: lambda %.6g, %d PCG iterations (rel %.2e)\n", qmax, lambda, pit, rres);
         double scale = 0.0;
         if (ok2) {
           hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
