@@ -1,9 +1,8 @@
 # Builds libsim3opt.so (hipcc, gfx950), the CPU oracle and the C++ examples without Python.
 #   make                 -> sim3opt_amd/libsim3opt.so, oracle/liboracle_sim3.so
 #   make example         -> examples/direct_pgo (testDirectSim3Optimization on the g2o-named shim)
-#   make call_forms      -> tests/cxx/reference_call_forms (the reference's call forms against the
-#                           shim; EIGEN_INC=-I/usr/include/eigen3 for a real Eigen + Sophus)
-#   make ba_call_forms   -> tests/cxx/reference_ba_call_forms (ba_demo's call forms against the BA shim)
+#   make conformance     -> tests/cxx/shim_conformance, tests/cxx/ba_shim_conformance (one block per
+#                           method of the g2o-named shims; EIGEN_INC=-I/usr/include/eigen3 for a real Eigen)
 #   make LIB=/some/where/libsim3opt.so   builds the library elsewhere (used by the tests)
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := sim3opt_amd/csrc
@@ -26,16 +25,14 @@ example: $(LIB) examples/direct_pgo.cpp include/sim3opt_g2o.hpp
 	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude examples/direct_pgo.cpp -L$(LIBDIR) -lsim3opt \
 	    -Wl,-rpath,$(LIBDIR) -o examples/direct_pgo
 
-call_forms: $(LIB) tests/cxx/reference_call_forms.cpp include/sim3opt_g2o.hpp
-	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude $(EIGEN_INC) tests/cxx/reference_call_forms.cpp \
-	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/reference_call_forms
-
-ba_call_forms: $(LIB) tests/cxx/reference_ba_call_forms.cpp include/sim3opt_g2o_ba.hpp
-	g++ -std=c++17 -Wall -DSIM3OPT_G2O_BA_NAMES -Iinclude $(EIGEN_INC) tests/cxx/reference_ba_call_forms.cpp \
-	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/reference_ba_call_forms
+conformance: $(LIB) tests/cxx/shim_conformance.cpp tests/cxx/ba_shim_conformance.cpp include/sim3opt_g2o.hpp include/sim3opt_g2o_ba.hpp
+	g++ -std=c++17 -Wall -DSIM3OPT_G2O_NAMES -Iinclude $(EIGEN_INC) tests/cxx/shim_conformance.cpp \
+	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/shim_conformance
+	g++ -std=c++17 -Wall -DSIM3OPT_G2O_BA_NAMES -Iinclude $(EIGEN_INC) tests/cxx/ba_shim_conformance.cpp \
+	    -L$(LIBDIR) -lsim3opt -Wl,-rpath,$(LIBDIR) -o tests/cxx/ba_shim_conformance
 
 clean:
-	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo tests/cxx/reference_call_forms \
-	    tests/cxx/reference_ba_call_forms
+	rm -f sim3opt_amd/libsim3opt.so oracle/liboracle_sim3.so examples/direct_pgo tests/cxx/shim_conformance \
+	    tests/cxx/ba_shim_conformance
 
-.PHONY: all example call_forms ba_call_forms clean
+.PHONY: all example conformance clean

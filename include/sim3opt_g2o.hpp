@@ -27,7 +27,7 @@
 // q.x() .. q.w() works -- Eigen at the user's site, or the fixed-size mock the tests compile against
 // (tests/mock_eigen; this image has no Eigen).  Return types (rotation(), translation(),
 // G2oVertexScaleTrans::estimate()) are Eigen's when <Eigen/Core> and <Eigen/Geometry> are on the
-// include path, else the small types below.  tests/cxx/reference_call_forms.cpp is the compile test.
+// include path, else the small types below.  tests/cxx/shim_conformance.cpp is the conformance test.
 //
 // How the stepwise optimizers map onto the library (kitti_surf.cpp:774-886): an optimizer of
 // G2oVertexScaleTrans / G2oEdgeScaleTrans is a Sim(3) graph whose rotations are frozen

@@ -1,8 +1,9 @@
 """The reference-side binding (include/sim3opt_g2o.hpp) in action: examples/direct_pgo.cpp is
 testDirectSim3Optimization (kitti_surf.cpp:542-709) on the g2o-named shim without any Eigen;
-tests/cxx/reference_call_forms.cpp holds the reference's own call forms (direct and stepwise
-builders, kitti_surf.cpp:552-701, :726-886, :1020-1075) and is compiled against a tests-only
-fixed-size Eigen / Sophus mock (tests/mock_eigen) and, where it is installed, against real Eigen."""
+tests/cxx/shim_conformance.cpp and tests/cxx/ba_shim_conformance.cpp are conformance programs of
+the two shims (one block per method the reference's callers use; then the pipelines
+end to end on a GPU), compiled against a tests-only fixed-size Eigen / Sophus mock (tests/mock_eigen)
+and, where it is installed, against real Eigen."""
 import os
 import subprocess
 
@@ -54,13 +55,15 @@ def test_shim_example_runs_direct_pgo(tmp_path):
     assert np.abs(rows[:, 1] - G.get_vertices()[:, 7]).max() < 1e-15
 
 
-# ------------------------------------------------------------------ the reference's call forms
-def compile_call_forms(tmp_path, eigen_inc):
-    exe = str(tmp_path / "reference_call_forms")
+# ------------------------------------------------------------------ conformance of the g2o-named shims
+def compile_conformance(tmp_path, eigen_inc, ba=False):
+    name = "ba_shim_conformance" if ba else "shim_conformance"
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "sim3opt_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-DSIM3OPT_G2O_NAMES",
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror",
+                           "-DSIM3OPT_G2O_BA_NAMES" if ba else "-DSIM3OPT_G2O_NAMES",
                            "-I" + os.path.join(ROOT, "include")] + eigen_inc +
-                          [os.path.join(ROOT, "tests", "cxx", "reference_call_forms.cpp"), "-L" + libdir,
+                          [os.path.join(ROOT, "tests", "cxx", name + ".cpp"), "-L" + libdir,
                            "-lsim3opt", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -68,35 +71,36 @@ def compile_call_forms(tmp_path, eigen_inc):
 MOCK = ["-I" + os.path.join(ROOT, "tests", "mock_eigen")]
 
 
-def test_reference_call_forms_compile_against_the_mock(tmp_path):
-    """`esim->information() = matLambdasim`, `g2o::Sim3 Siw(Rcw, tcw, 1.0)`, `.rotation().coeffs()`,
-    `vST->Rw2i = Sophus::SO3d(Rcw)`, G2oVertexScale / G2oEdgeScaleTrans ...: all of it compiles (-Werror)
-    and links; without a GPU the program fails loudly at initializeOptimization."""
-    import torch
-    exe = compile_call_forms(tmp_path, MOCK)
-    if torch.cuda.is_available():
-        pytest.skip("GPU present: covered by the gpu test")
-    r = subprocess.run([exe, K.FIXTURE, str(tmp_path) + "/", "1"], capture_output=True, text=True)
-    assert r.returncode != 0
-
-
-def test_reference_call_forms_compile_against_real_eigen(tmp_path):
+def real_eigen():
     inc = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3")
            if os.path.exists(os.path.join(d, "Eigen", "Core"))]
     if not inc:
         pytest.skip("no Eigen in this image (SURVEY.md 0.2): the mock stands in")
+    return inc[0]
+
+
+def test_shim_conformance_host_part(tmp_path):
+    """One block per method of SURVEY.md 8(b)'s list -- `Sim3(R, t, s)`, `information() = M` for
+    1 x 1 / 4 x 4 / 7 x 7, `rotation().coeffs().transpose()`, `setVertex`, `optimizer.vertex(id)`,
+    warm-start `setEstimate`, the solver-stack tags, refusals -- on a five-vertex ring, compiled
+    -Werror against the Eigen mock; needs no GPU."""
+    exe = compile_conformance(tmp_path, MOCK)
+    r = subprocess.run([exe, "host", K.FIXTURE], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 failed" in r.stdout, r.stdout + r.stderr
+
+
+def test_shim_conformance_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    exe = compile_conformance(tmp_path, MOCK)
+    r = subprocess.run([exe, "ring"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no usable HIP device" in r.stderr
+
+
+def test_shim_conformance_compiles_against_real_eigen(tmp_path):
     # Sophus is still the mock's (tests/mock_eigen/sophus includes "../Eigen/..." relatively)
-    compile_call_forms(tmp_path, ["-I" + inc[0]] + MOCK)
-
-
-def compile_ba_call_forms(tmp_path, eigen_inc):
-    exe = str(tmp_path / "reference_ba_call_forms")
-    libdir = os.path.join(ROOT, "sim3opt_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-DSIM3OPT_G2O_BA_NAMES",
-                           "-I" + os.path.join(ROOT, "include")] + eigen_inc +
-                          [os.path.join(ROOT, "tests", "cxx", "reference_ba_call_forms.cpp"), "-L" + libdir,
-                           "-lsim3opt", "-Wl,-rpath," + libdir, "-o", exe])
-    return exe
+    compile_conformance(tmp_path, ["-I" + real_eigen()] + MOCK)
 
 
 def write_keyframe_bal(tmp_path):
@@ -111,35 +115,41 @@ def write_keyframe_bal(tmp_path):
     return path
 
 
-def test_ba_call_forms_compile_against_the_mock(tmp_path):
-    """ba_demo's forms (bal_example.cpp:71-238) -- BlockSolver_6_3, CameraParameters, VertexSE3Expmap,
-    VertexSBAPointXYZ, EdgeProjectXYZ2UV + RobustKernelHuber, SE3Quat -- compile (-Werror) and link
-    against include/sim3opt_g2o_ba.hpp; without a GPU the program fails loudly."""
+def test_ba_shim_conformance_host_part(tmp_path):
+    """ba_demo's classes (bal_example.cpp:71-238) -- BlockSolver_6_3, CameraParameters, VertexSE3Expmap,
+    VertexSBAPointXYZ, EdgeProjectXYZ2UV + RobustKernelHuber, SE3Quat -- one block each on a
+    three-camera toy scene, compiled -Werror against the Eigen mock; needs no GPU."""
+    exe = compile_conformance(tmp_path, MOCK, ba=True)
+    r = subprocess.run([exe, "host"], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 failed" in r.stdout, r.stdout + r.stderr
+
+
+def test_ba_shim_conformance_fails_loudly_without_gpu(tmp_path):
     import torch
-    exe = compile_ba_call_forms(tmp_path, MOCK)
     if torch.cuda.is_available():
-        pytest.skip("GPU present: covered by the gpu test")
-    r = subprocess.run([exe, write_keyframe_bal(tmp_path), str(tmp_path / "poses.txt")], capture_output=True, text=True)
-    assert r.returncode == 3 and "optimize failed" in r.stderr or "initializeOptimization failed" in r.stderr
+        pytest.skip("GPU present: covered by the gpu tests")
+    exe = compile_conformance(tmp_path, MOCK, ba=True)
+    r = subprocess.run([exe, "bal", write_keyframe_bal(tmp_path), str(tmp_path / "poses.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and ("optimize failed" in r.stderr or "initializeOptimization failed" in r.stderr)
 
 
-def test_ba_call_forms_compile_against_real_eigen(tmp_path):
-    inc = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3")
-           if os.path.exists(os.path.join(d, "Eigen", "Core"))]
-    if not inc:
-        pytest.skip("no Eigen in this image (SURVEY.md 0.2): the mock stands in")
-    compile_ba_call_forms(tmp_path, ["-I" + inc[0]])
+def test_ba_shim_conformance_compiles_against_real_eigen(tmp_path):
+    compile_conformance(tmp_path, ["-I" + real_eigen()], ba=True)
 
 
 @pytest.mark.gpu
-def test_ba_call_forms_run(tmp_path):
-    """The g2o-named builder and the C-ABI / Python path give the same optimisation."""
+def test_ba_shim_runs(tmp_path):
+    """The g2o-named builder and the C-ABI / Python path give the same optimisation (a BAL file of
+    the three fixture keyframes); the toy scene with exact observations returns to the truth."""
     import re
     from sim3opt_amd import lib as L
-    exe = compile_ba_call_forms(tmp_path, MOCK)
+    exe = compile_conformance(tmp_path, MOCK, ba=True)
+    r = subprocess.run([exe, "toy"], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 failed" in r.stdout, r.stdout + r.stderr
     bal = write_keyframe_bal(tmp_path)
     out = str(tmp_path / "poses.txt")
-    r = subprocess.run([exe, bal, out, "5"], capture_output=True, text=True)
+    r = subprocess.run([exe, "bal", bal, out, "5"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     m = re.search(r"ba: chi2 (\S+) -> (\S+) in (\d+) iterations", r.stdout)
     b = L.BundleAdjuster()
@@ -168,30 +178,34 @@ def test_makefile_builds_a_loadable_library(tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_call_forms_run(tmp_path):
-    """The direct builder gives the same chi2 as the C-ABI path; the stepwise builders run their
-    stages (scale null vector, scale + translation LM with frozen rotations, warm-started Sim(3) LM)
-    and end far below the direct run's local minimum, as the reference's README says they should."""
+def test_shim_runs_the_reference_pipelines(tmp_path):
+    """Through the g2o-named classes: a five-vertex ring with exact constraints is solved to its
+    truth; on the KITTI-00 fixture the all-at-once Sim(3) run equals the C-ABI path, and the staged
+    runs (scale null vector, scale + translation LM with frozen rotations, warm-started Sim(3) LM)
+    end far below the all-at-once run's local minimum, as the reference's README says they should."""
     import re
-    from sim3opt_amd import lib as L
-    exe = compile_call_forms(tmp_path, MOCK)
-    r = subprocess.run([exe, K.FIXTURE, str(tmp_path) + "/", "1"], capture_output=True, text=True)
+    from sim3opt_amd import lib as L, sim3np as S3
+    exe = compile_conformance(tmp_path, MOCK)
+    r = subprocess.run([exe, "ring"], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 failed" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "kitti", K.FIXTURE, str(tmp_path) + "/", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
-    m = re.search(r"direct: chi2 (\S+) -> (\S+) in (\d+) iterations", r.stdout)
+    m = re.search(r"all-at-once: chi2 (\S+) -> (\S+) after (\d+) iterations", r.stdout)
     assert m and abs(float(m.group(1)) - 169.9259622) < 1e-6 and int(m.group(3)) == 100
     G = L.Graph()
     G.load_kitti_direct(K.FIXTURE, True)
     G.initialize()
     G.optimize(100)
-    # (the builder's states went quaternion -> 3x3 matrix -> quaternion through the mock and its
-    # odometry measurements were composed by the shim: last-bit differences in the inputs, which
-    # this configuration amplifies to 1e-3 in the final chi2 -- DESIGN.md section 2)
-    assert abs(float(m.group(2)) - G.stats()[-1].chi2_after) < 5e-3 * G.stats()[-1].chi2_after
-    st = re.findall(r"stepwise \((\d) optimizers\): scale sigma ratio (\S+), scale-trans chi2 (\S+) -> (\S+), final chi2 (\S+)", r.stdout)
+    # the shim hands the loader's states and constraints over unchanged: the same run, bit for bit
+    assert abs(float(m.group(2)) - G.stats()[-1].chi2_after) < 1e-9 * G.stats()[-1].chi2_after
+    rows = np.loadtxt(str(tmp_path / "all_at_once.txt"), comments="%")
+    Swc = S3.inv(G.get_vertices())
+    assert np.abs(rows[:, 2:5] - Swc[:, 4:7]).max() < 1e-12 and np.abs(rows[:, 1] - G.get_vertices()[:, 7]).max() < 1e-15
+    st = re.findall(r"staged \((\d) stages\): sigma ratio (\S+), scale\+translation chi2 (\S+) -> (\S+), final chi2 (\S+)", r.stdout)
     assert [s[0] for s in st] == ["2", "3"]
     for s in st:
         assert float(s[3]) < float(s[2])  # the scale + translation stage reduces its chi2
-    assert float(st[1][4]) < float(m.group(2))  # stepwise + Sim(3) ends below the direct run
-    for f in ("direct_pure.txt", "stepwise_2solvers.txt", "stepwise_3solvers.txt"):
+    assert float(st[1][4]) < float(m.group(2))  # staged + Sim(3) ends below the all-at-once run
+    for f in ("all_at_once.txt", "staged_2.txt", "staged_3.txt"):
         rows = np.loadtxt(str(tmp_path / f), comments="%")
         assert rows.shape == (771, 9) and np.isfinite(rows).all()
