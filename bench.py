@@ -372,8 +372,11 @@ def main():
         lo, hi = G.local_rows()  # rank 0's share (ranks are balanced by stored blocks)
         rows_local = hi - lo
         blocks_local = nnzb if world == 1 else (nnzb + world - 1) // world
-        # (the PCG's SpMV also reads r once for the fused r.z reduction)
-        spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + 3 * 7 * rows_local * 8
+        # (vectors: the input read once, q written once; with block-Jacobi / chain preconditioning the
+        # SpMV also reads r for the fused r.z reduction -- with the multigrid cycle r.z comes from the
+        # cycle's last pass and the SpMV does not load r)
+        n_vec = 2 if G.preconditioner_in_use() == 2 else 3
+        spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + n_vec * 7 * rows_local * 8
         # HBM bytes per SpMV launch from the last rocprofv3 --pmc collection (separate passes;
         # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r2_pmc_spmv.json
         traffic = None
@@ -391,6 +394,9 @@ def main():
             ach = spmv_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_spmv_span", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": ("profiles/r2_pmc_spmv.json: separate rocprofv3 --pmc passes of the same "
+                                       "kernel on the same graph, not a counter read in this run")
+                    if traffic is not None else None,
                     "avg_launch_ms": avg_ms, "launches": int(kt.n_spmv),
                     "algorithmic_bytes_per_launch": int(spmv_bytes)}
         out = {

@@ -200,16 +200,6 @@ int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, doubl
 /* solves (H + lambda I) x = b with the block-Jacobi PCG on the last linearisation */
 int sim3opt_solve(sim3opt_graph* g, double lambda, double* x /*7 nb*/, int32_t* iters,
                   double* rel_res);
-/* times `reps` back-to-back launches of the block-CSR SpMV kernel; returns mean ms */
-int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
-/* HBM read calibration over the same value array (bench only): mode 0 = 16 B/lane contiguous,
- * 1 = 8 B/lane contiguous, 2 = 8 B/lane on 49 of 64 lanes per 392-B block (the SpMV's shape) */
-int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
-/* Measurement prototype, not on the product path: the two-phase SpMV over upper-triangle storage
- * (csrc/symm_proto.hpp) on the last linearisation.  out[0] / out[1]: mean ms of phase 1 / phase 2 over
- * `reps` launches, out[2]: max difference to the product SpMV relative to max |q|, out[3]: bytes of its
- * stream.  Single GPU. */
-int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]);
 /* Preconditioner the PCG of this (initialized) graph uses: 0 block-Jacobi, 1 chain segments,
  * 2 aggregation multigrid (what `preconditioner = -1` resolved to); negative = error code. */
 int sim3opt_preconditioner_in_use(const sim3opt_graph* g);
@@ -282,10 +272,24 @@ int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t 
 /* block-row range [begin, end) this graph's rank owns (valid after initialize) */
 int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end);
 
+/* Returns the device blocks the library keeps for re-use (graphs that are re-initialised after growing
+ * by an edge find their predecessor's buffers, csrc/devmem.cpp; at most 1 GB) to the HIP runtime.
+ * Called automatically when the last sim3opt_graph / sim3opt_ba handle of the process is destroyed;
+ * call it yourself before allocating large device buffers of your own next to a live handle. */
+void sim3opt_release_device_cache(void);
+
 /* ---- reference-format I/O (host C++; the callers either side of the path) ---- */
 /* Builds the graph of testDirectSim3Optimization                   kitti_surf.cpp:562-670
  * from <dir>/cc.txt, <dir>/framePoses.txt (or framePoses_kf.txt), <dir>/loopConstraints.txt. */
 int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int32_t use_one_constraint);
+/* Consistency graph against numbers the reference wrote itself: vertices = the KITTI ground-truth
+ * poses (<dir>/gt_kf.txt, or 00.txt; 3x4 Pc2w rows, kitti_surf.cpp:1164-1190) as S_iw = (Rw2c, tw2c, 1);
+ * edges = line 1 of every <dir>/loopConstraints.txt record, i.e. DCM2Euler(Pw2c[f2] Pw2c[f1]^-1) + its
+ * translation as the reference's detector printed them from the same ground truth
+ * (kittiDetector.h:1051-1060), v0 = frame 1, v1 = frame 2, scale 1.  Every residual of this graph
+ * vanishes to the 8 decimals of the file iff the Euler convention, compose, inverse and edge
+ * orientation used by sim3opt_load_kitti_direct are the reference's.  Host only. */
+int sim3opt_load_kitti_gt_loops(sim3opt_graph* g, const char* dir);
 /* Writes "kfid s tx ty tz qx qy qz qw" rows (S_wi of each estimate)  kitti_surf.cpp:678-701;
  * precision: 17 significant digits (the reference prints 6). image_ids may be NULL. */
 int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids);

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/sim3opt.h"
+#include "devmem.hpp"
 #include "direct.hpp"
 
 namespace sim3opt_bundle {
@@ -633,8 +634,9 @@ struct Problem {
 
   ~Problem() { release(); }
   void release() {
+    if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : owned)
-      if (p) (void)hipFree(p);
+      if (p) sim3opt::dev_free(p);  // (the library's block cache: an out-of-memory hipMalloc elsewhere flushes it)
     owned.clear();
     if (h_sc) (void)hipHostFree(h_sc);
     h_sc = nullptr;
@@ -648,13 +650,13 @@ struct Problem {
 
   template <typename T>
   int up(T*& d, const std::vector<T>& h) {
-    BA_HIPCHK(hipMalloc((void**)&d, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    BA_HIPCHK(sim3opt::dev_malloc((void**)&d, sizeof(T) * std::max<size_t>(h.size(), 1)));
     owned.push_back(d);
     if (!h.empty()) BA_HIPCHK(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return SIM3OPT_OK;
   }
   int alloc(double*& d, size_t n) {
-    BA_HIPCHK(hipMalloc((void**)&d, sizeof(double) * std::max<size_t>(n, 1)));
+    BA_HIPCHK(sim3opt::dev_malloc((void**)&d, sizeof(double) * std::max<size_t>(n, 1)));
     owned.push_back(d);
     BA_HIPCHK(hipMemset(d, 0, sizeof(double) * std::max<size_t>(n, 1)));
     return SIM3OPT_OK;
@@ -724,7 +726,7 @@ struct Problem {
     int rc;
 #define BCHK(call) do { rc = (call); if (rc) return rc; } while (0)
     BCHK(up(d_cams, cams));
-    BA_HIPCHK(hipMalloc((void**)&d_cams_bk, sizeof(Cam) * NC)); owned.push_back(d_cams_bk);
+    BA_HIPCHK(sim3opt::dev_malloc((void**)&d_cams_bk, sizeof(Cam) * NC)); owned.push_back(d_cams_bk);
     BCHK(up(d_pts, pts));
     BCHK(alloc(d_pts_bk, 3 * (size_t)NP));
     BCHK(up(d_uv, uv));
@@ -793,9 +795,12 @@ struct Problem {
     grid_chi = std::max(1, std::min(1024, (NO + WG - 1) / WG));
     BCHK(alloc(d_pa, 1024)); BCHK(alloc(d_pb, 1024)); BCHK(alloc(d_pc, 1024));
 #undef BCHK
-    BA_HIPCHK(hipMalloc((void**)&d_sc, sizeof(Scal))); owned.push_back(d_sc);
+    BA_HIPCHK(sim3opt::dev_malloc((void**)&d_sc, sizeof(Scal))); owned.push_back(d_sc);
     BA_HIPCHK(hipMemset(d_sc, 0, sizeof(Scal)));
     BA_HIPCHK(hipHostMalloc((void**)&h_sc, sizeof(Scal)));
+    // the uploads and memsets above ran on the null stream, the kernels run on a non-blocking one:
+    // order them (engine.hip ends its init the same way)
+    BA_HIPCHK(hipDeviceSynchronize());
     ready = true;
     return SIM3OPT_OK;
   }
@@ -968,11 +973,18 @@ void sim3opt_ba_options_default(sim3opt_ba_options* o) {
 
 sim3opt_ba* sim3opt_ba_create(void) {
   sim3opt_ba* b = new (std::nothrow) sim3opt_ba();
-  if (b) sim3opt_ba_options_default(&b->opt);
+  if (b) {
+    sim3opt_ba_options_default(&b->opt);
+    sim3opt::handle_count(+1);
+  }
   return b;
 }
 
-void sim3opt_ba_destroy(sim3opt_ba* b) { delete b; }
+void sim3opt_ba_destroy(sim3opt_ba* b) {
+  if (!b) return;
+  delete b;
+  if (sim3opt::handle_count(-1) == 0) sim3opt::dev_cache_release();
+}
 
 const char* sim3opt_ba_last_error(const sim3opt_ba* b) { return b ? b->err.c_str() : "null problem"; }
 
@@ -998,6 +1010,7 @@ int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, 
     if (b) b->err = "ba_set_problem: bad argument";
     return SIM3OPT_ERR_ARG;
   }
+  try {
   for (int32_t o = 0; o < n_obs; ++o)
     if (obs_cam[o] < 0 || obs_cam[o] >= n_cams || obs_point[o] < 0 || obs_point[o] >= n_points) {
       b->err = "ba_set_problem: observation index out of range";  // (the reference asserts, :140-143)
@@ -1027,15 +1040,22 @@ int sim3opt_ba_set_problem(sim3opt_ba* b, int32_t n_cams, const double* cam_qt, 
   b->cam_fixed.assign(n_cams, 0);
   b->stats.clear();
   return SIM3OPT_OK;
+  } catch (...) {  // nothing crosses the C boundary
+    b->err = "ba_set_problem: out of host memory"; return SIM3OPT_ERR_ARG;
+  }
 }
 
 int sim3opt_ba_set_fixed_cameras(sim3opt_ba* b, const uint8_t* fixed) {
   if (!b || !fixed) return SIM3OPT_ERR_ARG;
+  try {
   if (b->nc() < 1) { b->err = "ba_set_fixed_cameras: no problem set"; return SIM3OPT_ERR_STATE; }
   b->cam_fixed.assign(fixed, fixed + b->nc());
   for (auto& f : b->cam_fixed) f = f ? 1 : 0;
   b->release();  // the next call re-uploads
   return SIM3OPT_OK;
+  } catch (...) {  // nothing crosses the C boundary
+    b->err = "ba_set_fixed_cameras: out of host memory"; return SIM3OPT_ERR_ARG;
+  }
 }
 
 // The BAL file as ba_demo reads it (bal_example.cpp:104-189): "<cams> <points> <observations>", one
@@ -1051,10 +1071,31 @@ int sim3opt_ba_read_bal(sim3opt_ba* b, const char* path, double focal, double cx
     b->err = "BAL header";
     return SIM3OPT_ERR_IO;
   }
-  std::vector<int32_t> oc(no), op(no);
-  std::vector<double> uv(2 * (size_t)no), cams(7 * (size_t)nc), pts(3 * (size_t)np);
+  {  // counts the file cannot hold (every number takes at least two bytes) are refused before any
+     // allocation is sized from them
+    const long at = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const long long bytes = std::ftell(f);
+    std::fseek(f, at, SEEK_SET);
+    const long long need = 2 * (4LL * no + 9LL * nc + 3LL * np);
+    if (at < 0 || bytes < need) {
+      std::fclose(f);
+      b->err = "BAL header: counts exceed the file";
+      return SIM3OPT_ERR_IO;
+    }
+  }
+  std::vector<int32_t> oc, op;
+  std::vector<double> uv, cams, pts;
+  try {
+    oc.resize((size_t)no); op.resize((size_t)no);
+    uv.resize(2 * (size_t)no); cams.resize(7 * (size_t)nc); pts.resize(3 * (size_t)np);
+  } catch (const std::exception&) {
+    std::fclose(f);
+    b->err = "BAL file: out of host memory";
+    return SIM3OPT_ERR_ARG;
+  }
   bool ok = true;
-  for (int o = 0; o < no && ok; ++o) ok = std::fscanf(f, "%d %d %lf %lf", &oc[o], &op[o], &uv[2 * o], &uv[2 * o + 1]) == 4;
+  for (size_t o = 0; o < (size_t)no && ok; ++o) ok = std::fscanf(f, "%d %d %lf %lf", &oc[o], &op[o], &uv[2 * o], &uv[2 * o + 1]) == 4;
   for (int c = 0; c < nc && ok; ++c) {
     double v[9];
     for (int j = 0; j < 9 && ok; ++j) ok = std::fscanf(f, "%lf", &v[j]) == 1;
@@ -1087,17 +1128,25 @@ int sim3opt_ba_dims(const sim3opt_ba* b, int32_t* n_cams, int32_t* n_points, int
 
 int sim3opt_ba_chi2(sim3opt_ba* b, double* chi2) {
   if (!b || !chi2) return SIM3OPT_ERR_ARG;
+  try {
   if (!b->ready) { int rc = b->initialize(); if (rc) return rc; }
   return b->chi2(chi2);
+  } catch (...) {  // nothing crosses the C boundary
+    b->err = "ba_chi2: out of host memory or internal error"; return SIM3OPT_ERR_ARG;
+  }
 }
 
 int sim3opt_ba_optimize(sim3opt_ba* b, int32_t max_iters) {
   if (!b) return 0;
+  try {
   b->err.clear();
   if (max_iters < 1 || b->no() < 1) return -1;
   if (!b->ready) { int rc = b->initialize(); if (rc) return 0; }
   const int n = b->optimize(max_iters);
   return n < 0 ? 0 : n;
+  } catch (...) {  // nothing crosses the C boundary
+    b->err = "ba_optimize: out of host memory or internal error"; return 0;
+  }
 }
 
 int sim3opt_ba_get_cameras(const sim3opt_ba* b, double* cam_qt) {

@@ -10,8 +10,10 @@
 #include <vector>
 
 #include "../../include/sim3opt.h"
+#include "../../include/sim3opt_bench.h"
 #include "amg.hpp"
 #include "comm.hpp"
+#include "devmem.hpp"
 #include "direct.hpp"
 #include "engine.hpp"
 #include "graph.hpp"
@@ -143,11 +145,20 @@ void sim3opt_options_default(sim3opt_options* o) {
 
 sim3opt_graph* sim3opt_create(void) {
   sim3opt_graph* g = new (std::nothrow) sim3opt_graph();
-  if (g) sim3opt_options_default(&g->opt);
+  if (g) {
+    sim3opt_options_default(&g->opt);
+    sim3opt::handle_count(+1);
+  }
   return g;
 }
 
-void sim3opt_destroy(sim3opt_graph* g) { delete g; }
+void sim3opt_destroy(sim3opt_graph* g) {
+  if (!g) return;
+  delete g;
+  if (sim3opt::handle_count(-1) == 0) sim3opt::dev_cache_release();  // the last handle of the process
+}
+
+void sim3opt_release_device_cache(void) { sim3opt::dev_cache_release(); }
 
 int sim3opt_set_options(sim3opt_graph* g, const sim3opt_options* o) {
   if (!g || !o) return fail(g, SIM3OPT_ERR_ARG, "set_options: null argument");
@@ -168,6 +179,7 @@ int sim3opt_get_options(const sim3opt_graph* g, sim3opt_options* o) {
 const char* sim3opt_last_error(const sim3opt_graph* g) { return g ? g->err.c_str() : "null graph"; }
 
 int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int32_t fixed) {
+  try {
   if (!g || !state) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: null argument");
   if (g->initialized) g->dirty = true;  // needs initializeOptimization() again, like g2o
   if (!state_ok(state)) return fail(g, SIM3OPT_ERR_ARG, "add_vertex: non-finite state or scale <= 0");
@@ -178,10 +190,14 @@ int sim3opt_add_vertex(sim3opt_graph* g, int32_t id, const double state[8], int3
   h.states.push_back(to_sim3(state));
   h.fixed.push_back(fixed ? 1 : 0);
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "add_vertex: out of host memory or internal error");
+  }
 }
 
 int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids, const double* states,
                          const uint8_t* fixed) {
+  try {
   if (!g || n < 0 || (n > 0 && !states)) return fail(g, SIM3OPT_ERR_ARG, "add_vertices: bad argument");
   HostGraph& h = g->host;
   h.vid.reserve(h.vid.size() + n);
@@ -195,18 +211,26 @@ int sim3opt_add_vertices(sim3opt_graph* g, int32_t n, const int32_t* ids, const 
     if (rc != SIM3OPT_OK) return rc;
   }
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "add_vertices: out of host memory or internal error");
+  }
 }
 
 int sim3opt_add_edge(sim3opt_graph* g, int32_t id_v0, int32_t id_v1, const double meas[8],
                      const double* info77, int32_t kernel, double kernel_delta) {
+  try {
   if (!g || !meas) return fail(g, SIM3OPT_ERR_ARG, "add_edge: null argument");
   if (g->initialized) g->dirty = true;
   return add_edge_impl(g, id_v0, id_v1, meas, info77, kernel, kernel_delta);
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "add_edge: out of host memory or internal error");
+  }
 }
 
 int sim3opt_add_edges(sim3opt_graph* g, int32_t m, const int32_t* id_v0, const int32_t* id_v1,
                       const double* meas, const double* info, int32_t kernel,
                       double kernel_delta) {
+  try {
   if (!g || m < 0 || (m > 0 && (!id_v0 || !id_v1 || !meas)))
     return fail(g, SIM3OPT_ERR_ARG, "add_edges: bad argument");
   if (g->initialized) g->dirty = true;
@@ -220,6 +244,9 @@ int sim3opt_add_edges(sim3opt_graph* g, int32_t m, const int32_t* id_v0, const i
     if (rc != SIM3OPT_OK) return rc;
   }
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "add_edges: out of host memory or internal error");
+  }
 }
 
 int32_t sim3opt_num_vertices(const sim3opt_graph* g) { return g ? g->host.nv() : 0; }
@@ -227,14 +254,19 @@ int32_t sim3opt_num_edges(const sim3opt_graph* g) { return g ? g->host.ne() : 0;
 
 int sim3opt_get_edge(const sim3opt_graph* g, int32_t k, int32_t* id_v0, int32_t* id_v1,
                      double meas[8]) {
+  try {
   if (!g || k < 0 || k >= g->host.ne()) return SIM3OPT_ERR_ARG;
   if (id_v0) *id_v0 = g->host.vid[g->host.ev0[k]];
   if (id_v1) *id_v1 = g->host.vid[g->host.ev1[k]];
   if (meas) from_sim3(g->host.meas[k], meas);
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return SIM3OPT_ERR_ARG;
+  }
 }
 
 int sim3opt_initialize(sim3opt_graph* g) {
+  try {
   if (!g) return SIM3OPT_ERR_ARG;
   const bool trace = std::getenv("SIM3OPT_INIT_TRACE") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -263,9 +295,13 @@ int sim3opt_initialize(sim3opt_graph* g) {
   if (!g->engine) return status;
   g->initialized = true;
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "initialize: out of host memory or internal error");
+  }
 }
 
 int sim3opt_optimize(sim3opt_graph* g, int32_t max_iters) {
+  try {
   if (!g) return 0;
   if (!g->initialized) {
     // g2o: optimize() on an uninitialised / empty problem returns -1
@@ -277,6 +313,9 @@ int sim3opt_optimize(sim3opt_graph* g, int32_t max_iters) {
   if (g->dirty) { g->err = "optimize: graph changed, call sim3opt_initialize again"; return 0; }
   const int rc = engine_optimize(g->engine, max_iters, g->stats, g->err);
   return rc < 0 ? 0 : rc;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    (void)fail(g, SIM3OPT_ERR_ARG, "optimize: out of host memory or internal error"); return 0;
+  }
 }
 
 int sim3opt_get_vertex(sim3opt_graph* g, int32_t id, double state[8]) {
@@ -371,6 +410,7 @@ int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* 
 
 int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks,
                            int32_t* rowptr, int32_t* colidx) {
+  try {
   if (!g) return SIM3OPT_ERR_ARG;
   Structure st;
   if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
@@ -379,6 +419,9 @@ int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_b
   if (rowptr) std::memcpy(rowptr, st.rowptr.data(), sizeof(int32_t) * (size_t)(st.nb + 1));
   if (colidx) std::memcpy(colidx, st.colidx.data(), sizeof(int32_t) * (size_t)st.nnzb);
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "system_pattern: out of host memory or internal error");
+  }
 }
 
 int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
@@ -416,6 +459,7 @@ int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], in
                         int32_t* colptr, int32_t* lrow, int32_t* srcptr, int32_t* src,
                         int32_t* pairptr, int32_t* pa, int32_t* pb, int32_t* gptr, int32_t* lcolp,
                         int32_t* rptr, int32_t* cells) {
+  try {
   if (!g || !dims) return fail(g, SIM3OPT_ERR_ARG, "direct_plan: bad argument");
   Structure st;
   if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
@@ -436,10 +480,14 @@ int sim3opt_direct_plan(sim3opt_graph* g, int64_t max_pairs, int64_t dims[8], in
   out(pairptr, P.pairptr); out(pa, P.pa); out(pb, P.pb); out(gptr, P.gptr); out(lcolp, P.lcolp);
   out(rptr, P.rptr); out(cells, P.cells);
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "direct_plan: out of host memory or internal error");
+  }
 }
 
 int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels, int32_t* rows,
                           int64_t* blocks, int32_t* aggregate_of_row) {
+  try {
   if (!g || !n_levels || capacity < 0) return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: bad argument");
   Structure st;
   if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
@@ -456,6 +504,9 @@ int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels,
   }
   if (aggregate_of_row) std::memcpy(aggregate_of_row, levels[0].agg.data(), sizeof(int32_t) * (size_t)st.nb);
   return SIM3OPT_OK;
+  } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
+    return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: out of host memory or internal error");
+  }
 }
 
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean) {

@@ -87,6 +87,14 @@ void dev_free(void* p) {
   }
 }
 
+int handle_count(int delta) {
+  static std::mutex mu;
+  static int n = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  n += delta;
+  return n;
+}
+
 void dev_cache_release() {
   Cache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);

@@ -14,5 +14,8 @@ namespace sim3opt {
 hipError_t dev_malloc(void** p, size_t bytes);
 void dev_free(void* p);
 void dev_cache_release();  // gives every cached block back to the driver
+// live sim3opt_graph / sim3opt_ba handles of the process (delta = +1 / -1; returns the new count):
+// the cache is released when the last one goes (sim3opt_release_device_cache does it on request)
+int handle_count(int delta);
 
 }  // namespace sim3opt

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
   if (UP) {
     for (int l = lv0; l < lv1; ++l) {
       const int q0 = A.rptr[l], q1 = A.rptr[l + 1];
-      if (trace) A.dbg[ti++] = wall_clock64();
+      if (trace && ti < 254) A.dbg[ti++] = wall_clock64();
       for (int q = q0; q < q1; ++q) {
         const int32_t* cell = A.cells + (size_t)LDL_ST * q;
         const int sa = cell[wave], sb = cell[wave + 1];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
           k += m;
         }
         __syncthreads();
-        if (trace) A.dbg[ti++] = wall_clock64();
+        if (trace && ti < 254) A.dbg[ti++] = wall_clock64();
         // ---- phase C: off-diagonal blocks of the cell times L(j,j)^-T ----
         {
           double dv[LDL_CS];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
       }
     }
   }
-  if (trace) A.dbg[ti++] = wall_clock64();
+  if (trace && ti < 254) A.dbg[ti++] = wall_clock64();
   if (DOWN) {
     for (int l = lv1 - 1; l >= lv0; --l) {
       const int c0 = A.lcolp[l], c1 = A.lcolp[l + 1];
@@ -319,5 +319,5 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
       __syncthreads();
     }
   }
-  if (trace) { A.dbg[ti++] = wall_clock64(); A.dbg[255] = ti; }
+  if (trace) { if (ti < 254) A.dbg[ti++] = wall_clock64(); A.dbg[255] = ti; }
 }

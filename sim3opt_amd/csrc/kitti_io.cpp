@@ -149,6 +149,77 @@ extern "C" int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int3
   return SIM3OPT_OK;
 }
 
+// Consistency graph of the loader's conventions against numbers the reference itself wrote:
+// line 1 of every loopConstraints.txt record is DCM2Euler(Pw2c[f2] Pw2c[f1]^-1) and its translation,
+// computed by the reference's detector from the KITTI ground truth (kittiDetector.h:1051-1060, 8
+// decimals; ReadCameraPose :599-624 inverts the 3x4 Pc2w row).  With the ground-truth poses as
+// vertices S_iw = (Rw2c, tw2c, 1) and those records as edges (v0 = frame 1, v1 = frame 2), every
+// residual log(C S_v0 S_v1^-1) vanishes to the file's precision -- if the Euler convention
+// (roteu2ro, kittiDetector.h:225-243), compose, inverse and the edge orientation are the reference's.
+extern "C" int sim3opt_load_kitti_gt_loops(sim3opt_graph* g, const char* dir) {
+  if (!g || !dir) return SIM3OPT_ERR_ARG;
+  const std::string d(dir);
+  // ground truth: "image_id r00 r01 r02 tx r10 ... tz" rows of the keyframes (gt_kf.txt, one comment
+  // line), or the full 00.txt (row number = image id, kitti_surf.cpp:1164-1190)
+  std::map<int, int> frame2v;
+  std::vector<std::string> lines;
+  const bool kf_file = read_lines(d + "/gt_kf.txt", lines);
+  if (!kf_file && !read_lines(d + "/00.txt", lines)) return SIM3OPT_ERR_IO;
+  int row = 0;
+  for (const std::string& ln : lines) {
+    if (blank(ln) || ln[0] == '%') continue;
+    std::istringstream is(ln);
+    int id = row;
+    if (kf_file) is >> id;
+    double P[12];
+    for (double& x : P) is >> x;
+    if (!is) return SIM3OPT_ERR_IO;
+    // Pw2c = Pc2w^-1 as a MATRIX inverse (ReadCameraPose's cv::Mat::inv(), kittiDetector.h:622): the
+    // file's 7-digit rotations are orthonormal to 1e-7 only
+    const double* M = P;  // rows (M[0..2], M[4..6], M[8..10]), translation M[3], M[7], M[11]
+    const double c00 = M[5] * M[10] - M[6] * M[9], c01 = M[6] * M[8] - M[4] * M[10], c02 = M[4] * M[9] - M[5] * M[8];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    if (!(std::fabs(det) > 1e-12)) return SIM3OPT_ERR_IO;
+    const double Rw2c[9] = {c00 / det, (M[2] * M[9] - M[1] * M[10]) / det, (M[1] * M[6] - M[2] * M[5]) / det,
+                            c01 / det, (M[0] * M[10] - M[2] * M[8]) / det, (M[2] * M[4] - M[0] * M[6]) / det,
+                            c02 / det, (M[1] * M[8] - M[0] * M[9]) / det, (M[0] * M[5] - M[1] * M[4]) / det};
+    Sim3 s;
+    sim3::quat_from_R(Rw2c, s.q);
+    for (int i = 0; i < 3; ++i) s.t[i] = -(Rw2c[3 * i] * P[3] + Rw2c[3 * i + 1] * P[7] + Rw2c[3 * i + 2] * P[11]);
+    s.s = 1.0;
+    double a[8];
+    to_array(s, a);
+    frame2v[id] = (int)frame2v.size();
+    const int rc = sim3opt_add_vertex(g, (int32_t)frame2v[id], a, row == 0);
+    if (rc != SIM3OPT_OK) return rc;
+    ++row;
+  }
+  lines.clear();
+  if (!read_lines(d + "/loopConstraints.txt", lines)) return SIM3OPT_ERR_IO;
+  std::vector<std::string> rec;
+  for (size_t ln = 5; ln < lines.size(); ++ln)
+    if (!blank(lines[ln])) rec.push_back(lines[ln]);
+  for (size_t k = 0; k + 3 < rec.size(); k += 4) {
+    unsigned f1, f2;
+    double gt[6];
+    if (std::sscanf(rec[k].c_str(), "%u %u %lf %lf %lf %lf %lf %lf", &f1, &f2, &gt[0], &gt[1], &gt[2],
+                    &gt[3], &gt[4], &gt[5]) != 8)
+      return SIM3OPT_ERR_IO;
+    auto i1 = frame2v.find((int)f1), i2 = frame2v.find((int)f2);
+    if (i1 == frame2v.end() || i2 == frame2v.end()) return SIM3OPT_ERR_IO;
+    double R[9], a[8];
+    euler_rpy_to_R(gt[0], gt[1], gt[2], R);
+    Sim3 C;
+    sim3::quat_from_R(R, C.q);
+    C.t[0] = gt[3]; C.t[1] = gt[4]; C.t[2] = gt[5];
+    C.s = 1.0;
+    to_array(C, a);
+    const int rc = sim3opt_add_edge(g, i1->second, i2->second, a, nullptr, SIM3OPT_KERNEL_NONE, 0.0);
+    if (rc != SIM3OPT_OK) return rc;
+  }
+  return sim3opt_num_edges(g) > 0 ? SIM3OPT_OK : SIM3OPT_ERR_IO;
+}
+
 extern "C" int sim3opt_write_poses(sim3opt_graph* g, const char* path, const int32_t* image_ids) {
   if (!g || !path) return SIM3OPT_ERR_ARG;
   const int32_t nv = sim3opt_num_vertices(g);

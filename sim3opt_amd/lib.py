@@ -144,6 +144,8 @@ SYMBOLS = {
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
     "sim3opt_partition_rows_equal": (C.c_int, [C.c_int32, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
+    "sim3opt_load_kitti_gt_loops": (C.c_int, [_vp, C.c_char_p]),
+    "sim3opt_release_device_cache": (None, []),
     "sim3opt_write_poses": (C.c_int, [_vp, C.c_char_p, _ip]),
     "sim3opt_stepwise_scale_init": (C.c_int, [_vp, _dp]),
     "sim3opt_read_keyframe_bin": (C.c_int, [C.c_char_p, _ip, _dp, _dp, _ip, C.POINTER(C.c_uint32), _dp,
@@ -518,6 +520,10 @@ class Graph:
     def load_kitti_direct(self, directory, use_one_constraint=True):
         self._chk(self._L.sim3opt_load_kitti_direct(self._g, os.fsencode(directory),
                                                     int(bool(use_one_constraint))))
+
+    def load_kitti_gt_loops(self, directory):
+        """Ground-truth poses + line 1 of every loop record: all residuals ~ 0 (a convention pin)."""
+        self._chk(self._L.sim3opt_load_kitti_gt_loops(self._g, os.fsencode(directory)))
 
     def stepwise_scale_init(self):
         """Stage 1 of the stepwise pipeline; returns the sigma_min/sigma_max estimate."""

@@ -22,8 +22,9 @@ def init(rank, world, port):
                             world_size=world)
 
 
-_RENDEZVOUS_MARKERS = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset",
-                       "connect() timed out", "Socket Timeout", "failed to connect", "The server socket has failed")
+# bind-race messages only: "Connection reset" / "Connection refused" are also what the survivors print
+# when a peer died AFTER the rendezvous -- a worker fault, which must not be retried
+_RENDEZVOUS_MARKERS = ("Address already in use", "EADDRINUSE", "The server socket has failed")
 
 
 def is_rendezvous_error(exc):

@@ -48,3 +48,18 @@ first45 = sorted(n for n in os.listdir(SRC) if n.startswith("KeyFrame") and n.en
 for name in first45:
     shutil.copyfile(os.path.join(SRC, name), os.path.join(DST, "keyframes45", name))
 print("keyframe files:", len(KF3), "+", len(first45))
+
+# rots.txt: `Rw2i` of every keyframe as the reference wrote it (kitti_surf.cpp:486-496, 6 significant
+# digits): the rows of the 45 committed keyframe files pin the pose block of sim3opt_read_keyframe_bin
+# to a reference-held number (a rots.txt row is the Rw2c of the .bin, not of
+# framePoses.txt)
+kept = {int(n[len("KeyFrame"):-len(".bin")]) for n in first45}
+with open(os.path.join(SRC, "rots.txt")) as f, open(os.path.join(DST, "rots_kf45.txt"), "w") as g:
+    g.write("% rows of data/map000000/rots.txt (image id, Rw2i row-major; written at kitti_surf.cpp:486-496) "
+            "for the 45 keyframes under keyframes45/\n")
+    nrot = 0
+    for ln in f:
+        if ln.strip() and int(ln.split()[0]) in kept:
+            g.write(ln.strip() + "\n")
+            nrot += 1
+print("rots rows kept", nrot)

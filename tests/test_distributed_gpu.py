@@ -22,11 +22,14 @@ def _free_port():
     return p
 
 
+COARSEST = ("SIM3OPT_AMG_COARSEST", "64")
+
+
 def _graph(prec=-1):
     from sim3opt_amd import synth
     synth.DRIFT_TARGET = 0.05
-    if prec == 2:  # large enough for a three-level hierarchy (1499 -> ~180 -> ~22 rows)
-        return synth.manhattan(1500, 15000, dims=(12, 12, 10))
+    if prec == 2:  # a three-level hierarchy with the dense level capped at 64 rows (COARSEST below):
+        return synth.manhattan(1500, 15000, dims=(12, 12, 10))  # 1499 -> 167 -> 18 rows
     return synth.manhattan(300, 2500, dims=(7, 7, 4), per_cell=4)
 
 
@@ -36,6 +39,8 @@ def _worker(rank, world, port, out, prec=-1):
     import dist_helpers as D
     from sim3opt_amd import lib as L
     D.init(rank, world, port)
+    if prec == 2:
+        os.environ[COARSEST[0]] = COARSEST[1]
     g = _graph(prec)
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
@@ -70,11 +75,15 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
     H.spawn_with_port_retry(
         lambda: mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True))
     res = [np.load(out + f".{r}.npz") for r in range(world)]
+    if prec == 2:
+        monkeypatch.setenv(*COARSEST)
     g = _graph(prec)
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     G.initialize()
+    if prec == 2:
+        assert len(G.amg_hierarchy()[0]) == 3
     chi0 = G.chi2()
     n = G.optimize(4)
     st = G.stats()
@@ -107,6 +116,8 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     import ctypes as C
     from sim3opt_amd import lib as L
     monkeypatch.setenv("SIM3OPT_FORCE_COMM", "1")
+    if prec == 2:
+        monkeypatch.setenv(*COARSEST)
     g = _graph(prec)
     uid = np.zeros(128, dtype=np.uint8)
     assert L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) == L.OK
