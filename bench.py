@@ -434,7 +434,16 @@ def main():
             npcg = max(sum(int(s.pcg_iters) for s in stats), 1)
             out["collectives_rank0"] = dict(ct, ms_per_lm_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / K,
                                             ms_per_pcg_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / npcg,
-                                            fraction_of_step=(ct["ms_allreduce"] + ct["ms_allgather"]) / (dt * 1e3))
+                                            fraction_of_step=(ct["ms_allreduce"] + ct["ms_allgather"]) / (dt * 1e3),
+                                            # payload of the buffers exchanged (whole buffer; a rank receives
+                                            # (N - 1) / N of an all-gather), per PCG iteration
+                                            bytes_per_pcg_iteration=(ct["bytes_allreduce"] + ct["bytes_allgather"]) / npcg)
+            # the partition the collectives serve: rows in breadth-first locality order, equal spans
+            _, _, bnd, cut = G.partition_plan(world)
+            out["partition"] = {"row_order": "breadth-first locality order", "rows": int(nb),
+                                "boundary_rows_per_rank": [int(x) for x in bnd],
+                                "halo_fraction_of_vector": float(bnd.sum()) / max(1, int(nb)),
+                                "cut_edges": int(cut), "cut_edge_fraction": float(cut) / max(1, len(g["v0"]))}
         if world == 1 and G.preconditioner_in_use() != 0 and not args.main_only:
             # same K steps with plain block-Jacobi PCG, for comparison (not part of `value`)
             J = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, preconditioner=0,

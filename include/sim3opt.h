@@ -68,12 +68,12 @@ typedef struct sim3opt_options {
   int32_t preconditioner;   /* -1    0 = 7x7 block-Jacobi, 1 = block-tridiagonal chain segments,
                                        2 = aggregation multigrid (pairwise-matched aggregates,
                                        Ad(S_v)-transported prolongation, dense coarsest level),
-                                       -1 = automatic, in the well-posed arithmetic only: multigrid
-                                       when the graph has more than 256 free vertices and coarsens
-                                       like a low-dimensional graph (level-1 blocks <= 0.3 x level-0
-                                       blocks: chains, chains with loops, Manhattan worlds -- not
-                                       expanders), chain segments for smaller nearly pure chains,
-                                       else block-Jacobi                                           */
+                                       -1 = automatic: multigrid when the graph has more than 256
+                                       free vertices and coarsens like a low-dimensional graph
+                                       (level-1 blocks <= 0.3 x level-0 blocks: chains, chains with
+                                       loops, Manhattan worlds -- not expanders), chain segments for
+                                       smaller nearly pure chains (well-posed arithmetic only), else
+                                       block-Jacobi                                                */
   int32_t chain_segment;    /* 256   rows per chain segment (2..256)                             */
   int32_t device;           /* -1    HIP device ordinal; -1 = current device             */
   int32_t verbose;          /* 0     1: one stderr line per LM iteration (setVerbose)    */
@@ -197,6 +197,8 @@ int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_b
  * block) and b (7 nb) to the host; block row k = k-th free vertex in insertion order */
 int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
                        double* b);
+/* (a graph that is row-partitioned over several ranks numbers its block rows in locality order
+ * instead: sim3opt_partition_plan(..., locality = 1, vertex_of_row, ...) gives the mapping) */
 /* solves (H + lambda I) x = b with the block-Jacobi PCG on the last linearisation */
 int sim3opt_solve(sim3opt_graph* g, double lambda, double* x /*7 nb*/, int32_t* iters,
                   double* rel_res);
@@ -269,6 +271,15 @@ int sim3opt_comm_allgather_plan(int32_t n_block_rows, int32_t world, int32_t* ro
 int sim3opt_partition_rows_equal(int32_t n_block_rows, int32_t world, int32_t* row_begin);
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin /*world+1*/);
+/* Row order and halo of the partition over `world` ranks (host only, may be called before
+ * initialize).  locality = 1: the block rows in the breadth-first locality order the partitioned path
+ * gives a graph with world > 1 (contiguous rank spans are slabs of the graph); 0: insertion order (what
+ * one rank uses: g2o's hessianIndex).  vertex_of_row (n_block_rows entries, may be NULL): vertex index
+ * (insertion order) of every block row; row_begin: world + 1; boundary_rows_of_rank[r]: rows of rank r
+ * with a neighbour on another rank -- what it sends per exchange of the partitioned PCG;
+ * *cut_edges: edges whose endpoints two ranks own (both linearise them). */
+int sim3opt_partition_plan(sim3opt_graph* g, int32_t world, int32_t locality, int32_t* vertex_of_row,
+                           int32_t* row_begin, int32_t* boundary_rows_of_rank, int64_t* cut_edges);
 /* block-row range [begin, end) this graph's rank owns (valid after initialize) */
 int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end);
 

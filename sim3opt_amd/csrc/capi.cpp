@@ -1,5 +1,6 @@
 // capi.cpp -- the C-ABI of libsim3opt (include/sim3opt.h): argument checking, the host graph
 // container and dispatch into the HIP engine.  No exceptions leave this file.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -283,7 +284,16 @@ int sim3opt_initialize(sim3opt_graph* g) {
     g->dirty = false;
   }
   t1 = now();
-  if (!build_structure(g->host, g->structure, g->err)) return SIM3OPT_ERR_STATE;
+  {
+    // a graph that is row-partitioned over several ranks gets its block rows in locality order
+    // (contiguous rank spans are then slabs of the graph: few cut edges, a small halo); one rank
+    // keeps g2o's insertion order.  SIM3OPT_ROW_ORDER=bfs / insertion overrides (tests, measurements).
+    bool local = g->comm_set && g->comm.world > 1;
+    if (const char* ev = std::getenv("SIM3OPT_ROW_ORDER")) local = std::string(ev) == "bfs";
+    std::vector<int32_t> order;
+    if (local) locality_order(g->host, order);
+    if (!build_structure(g->host, g->structure, g->err, local ? &order : nullptr)) return SIM3OPT_ERR_STATE;
+  }
   t2 = now();
   int status = SIM3OPT_OK;
   g->engine = engine_create(g->host, g->structure, g->opt, g->comm_set ? &g->comm : nullptr,
@@ -506,6 +516,38 @@ int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels,
   return SIM3OPT_OK;
   } catch (...) {  // (std::bad_alloc, std::length_error ...: nothing crosses the C boundary)
     return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: out of host memory or internal error");
+  }
+}
+
+int sim3opt_partition_plan(sim3opt_graph* g, int32_t world, int32_t locality, int32_t* vertex_of_row,
+                           int32_t* row_begin, int32_t* boundary_rows_of_rank, int64_t* cut_edges) {
+  try {
+    if (!g || world < 1) return fail(g, SIM3OPT_ERR_ARG, "partition_plan: bad argument");
+    std::vector<int32_t> order;
+    if (locality) locality_order(g->host, order);
+    Structure st;
+    if (!build_structure(g->host, st, g->err, locality ? &order : nullptr)) return SIM3OPT_ERR_STATE;
+    std::vector<int32_t> begin(world + 1), rows, seg;
+    partition_rows_equal(st.nb, world, begin.data());
+    boundary_rows(st.nb, st.rowptr.data(), st.colidx.data(), world, begin.data(), rows, seg);
+    if (vertex_of_row) std::memcpy(vertex_of_row, st.row2vertex.data(), sizeof(int32_t) * (size_t)st.nb);
+    if (row_begin) std::memcpy(row_begin, begin.data(), sizeof(int32_t) * (size_t)(world + 1));
+    if (boundary_rows_of_rank)
+      for (int32_t r = 0; r < world; ++r) boundary_rows_of_rank[r] = seg[r + 1] - seg[r];
+    if (cut_edges) {
+      auto owner = [&](int32_t row) {
+        return (int32_t)(std::upper_bound(begin.begin(), begin.end(), row) - begin.begin()) - 1;
+      };
+      int64_t cut = 0;
+      for (int32_t k : st.active) {
+        const int32_t a = st.hidx[g->host.ev0[k]], b = st.hidx[g->host.ev1[k]];
+        if (a >= 0 && b >= 0 && owner(a) != owner(b)) ++cut;
+      }
+      *cut_edges = cut;
+    }
+    return SIM3OPT_OK;
+  } catch (...) {
+    return fail(g, SIM3OPT_ERR_ARG, "partition_plan: out of host memory or internal error");
   }
 }
 

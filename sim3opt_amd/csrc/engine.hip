@@ -1004,6 +1004,23 @@ __global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restri
 
 __global__ void k_reset_fail(DevScalars* sc) { sc->fail = 0; }
 
+// Halo exchange of the row-partitioned PCG (round 3): the boundary rows of a vector (rows with a
+// neighbour on another rank, host list `brow`, grouped by owner) are packed into one buffer, that
+// buffer is all-gathered (each rank contributes its own segment), and every foreign boundary row is
+// written back into the full-length vector -- instead of all-gathering the whole vector.
+__global__ __launch_bounds__(WG) void k_halo_pack(int k0, int k1, const int32_t* __restrict__ brow,
+                                                  const double* __restrict__ vec, double* __restrict__ buf) {
+  const int t = blockIdx.x * WG + threadIdx.x;
+  const int k = k0 + t / 7, c = t % 7;
+  if (k < k1) buf[(size_t)7 * k + c] = vec[(size_t)7 * brow[k] + c];
+}
+__global__ __launch_bounds__(WG) void k_halo_unpack(int n, int own0, int own1, const int32_t* __restrict__ brow,
+                                                    const double* __restrict__ buf, double* __restrict__ vec) {
+  const int t = blockIdx.x * WG + threadIdx.x;
+  const int k = t / 7, c = t % 7;
+  if (k < n && (k < own0 || k >= own1)) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
+}
+
 // computeScale: sum_j x_j (lambda x_j + b_j)
 __global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
                                               const double* __restrict__ b, double lambda,
@@ -1165,6 +1182,14 @@ class Engine {
   int32_t r0 = 0, r1 = 0, e_lo = 0, e_hi = 0;
   std::vector<int32_t> row_begin;
   std::vector<int64_t> offs;
+  // halo exchange (world > 1): boundary rows of all ranks, grouped by owner; this rank's share is
+  // [halo_seg[rank], halo_seg[rank + 1]); halo_offs = 7 * halo_seg (doubles)
+  bool use_halo = false;
+  int32_t n_halo = 0;
+  std::vector<int32_t> halo_seg;
+  std::vector<int64_t> halo_offs;
+  int32_t* d_brow = nullptr;
+  double* d_halo = nullptr;
   // timing
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   // phase stamps of the LM loop (linearise | solve | update): recorded without waiting, read after
@@ -1182,7 +1207,7 @@ class Engine {
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                     d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
                     d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
-                    d_sub_first, d_sub_cnt, d_Gm};
+                    d_sub_first, d_sub_cnt, d_Gm, d_brow, d_halo};
     for (void* p : ptrs)
       if (p) dev_free(p);
     for (void* p : amg_owned)
@@ -1234,6 +1259,26 @@ class Engine {
     r1 = row_begin[comm.rank + 1];
     offs.resize(comm.world + 1);
     for (int r = 0; r <= comm.world; ++r) offs[r] = 7 * (int64_t)row_begin[r];
+    if (comm.world > 1 && !std::getenv("SIM3OPT_NO_HALO")) {
+      std::vector<int32_t> brow;
+      boundary_rows(nb, s.rowptr.data(), s.colidx.data(), comm.world, row_begin.data(), brow, halo_seg);
+      n_halo = (int32_t)brow.size();
+      halo_offs.resize(comm.world + 1);
+      for (int r = 0; r <= comm.world; ++r) halo_offs[r] = 7 * (int64_t)halo_seg[r];
+      // (worth it while the boundary is a fraction of the vector; a partition in insertion order of a
+      // graph without locality has nearly every row on it: the plain all-gather is cheaper then)
+      use_halo = n_halo > 0 && (int64_t)n_halo * 2 < nb;
+      if (use_halo) {
+        HIPCHK(upload(d_brow, brow));
+        int64_t padded = 0;
+        (void)allgather_equal_plan(halo_offs.data(), comm.world, nullptr, &padded);
+        HIPCHK(dev_malloc((void**)&d_halo, sizeof(double) * (size_t)std::max<int64_t>(padded, 7 * (int64_t)n_halo)));
+      }
+      if (opt.verbose)
+        std::fprintf(stderr, "sim3opt: rank %d of %d: rows [%d, %d) of %d, %d boundary rows in all (%.1f %%): %s\n",
+                     comm.rank, comm.world, r0, r1, nb, n_halo, 100.0 * n_halo / std::max(1, nb),
+                     use_halo ? "halo exchange" : "whole-vector all-gather");
+    }
     e_lo = (int32_t)((int64_t)ne * comm.rank / comm.world);
     e_hi = (int32_t)((int64_t)ne * (comm.rank + 1) / comm.world);
     // this rank linearises the edges incident to its rows and writes only its rows' blocks
@@ -1306,14 +1351,16 @@ class Engine {
       for (int32_t k = s.rowptr[i] + 1; k < s.rowptr[i + 1]; ++k)
         if (s.colidx[k] == i - 1) { ++chain_links; break; }
     const int64_t off_chain_edges = (nnzb - nb) / 2 - chain_links;
-    // (only in the well-posed arithmetic: as written, cond(H + lambda I) reaches 1e12 on KITTI, the
-    // recursive residual of a strongly preconditioned CG drifts from the true one, and LM leaves
-    // the exact-Cholesky trajectory at its second iteration -- measured)
-    // Automatic choice (well-posed arithmetic only): the multigrid hierarchy whenever the graph
-    // coarsens like a low-dimensional one (level-1 blocks <= 0.3 x level-0 blocks: chains, KITTI
-    // with its loops, Manhattan worlds -- not expanders such as config 2, where block-Jacobi
-    // converges in tens of iterations); graphs too small for a hierarchy (<= 256 rows) get chain
-    // segments if they are nearly pure chains; block-Jacobi otherwise.
+    // Automatic choice: the exact factorisation where it is cheap (KITTI-00, chain-like graphs); else
+    // the multigrid hierarchy whenever the graph coarsens like a low-dimensional one (level-1 blocks
+    // <= 0.3 x level-0 blocks: chains, Manhattan worlds -- not expanders such as config 2, where
+    // block-Jacobi converges in tens of iterations) -- in either arithmetic (round 3: with the
+    // coefficient as written the hierarchy sets up without a failing pivot on config 3 and every solve
+    // converges, 11 ... 690 iterations, where block-Jacobi stops at its 1000-iteration cap from the
+    // sixth LM iteration on; scripts/gpu_refarith_amg.py); graphs too small for a hierarchy
+    // (<= 256 rows) get chain segments if they are nearly pure chains -- in the well-posed arithmetic
+    // only: as written cond(H + lambda I) reaches 1e12 on a chain and the recursive residual of so
+    // strongly preconditioned a CG drifts from the true one --; block-Jacobi otherwise.
     // (naming a preconditioner asks for the PCG)
     const double it1 = inow();
     if (opt.linear_solver == 1 || (opt.linear_solver < 0 && opt.preconditioner < 0)) {
@@ -1322,7 +1369,7 @@ class Engine {
     }
     const double it2 = inow();
     if (!use_direct &&
-        (opt.preconditioner == 2 || (opt.preconditioner < 0 && opt.fix_small_angle_b != 0))) {
+        (opt.preconditioner == 2 || opt.preconditioner < 0)) {
       int rc = amg_init(s, opt.preconditioner < 0, err);
       if (rc) return rc;
     }
@@ -1627,6 +1674,8 @@ class Engine {
                        Lc.rowptr, Lc.colidx, Lc.vals, d_Ainv2);
     // pivot blocks of `amg_pivot` rows (14: 82 launches of 23 us for 1141 unknowns; 28: 41 of 47 us), then
     // 14, then 7 for the tail; an even number of steps would end in d_Ainv2: start from d_Ainv then
+    // (round 3: 32-row pivots inverted by the whole workgroup in LDS took 36 x 52 us -- the same 1.9 ms;
+    // profiles/r3_negative_results.log)
     int nsteps = 0;
     for (int k0 = 0; k0 < nd;) { k0 += nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7); ++nsteps; }
     double *src = d_Ainv2, *dst = d_Ainv;
@@ -1760,7 +1809,7 @@ class Engine {
   int amg_apply(std::string& err) {
     amg_status = SIM3OPT_OK;
     if (comm.active()) {
-      int rc = comm.allgatherv(d_z, offs, stream, err);
+      int rc = exchange_rows(d_z, err);
       if (rc) return rc;
     }
     if (amg_additive) {
@@ -1775,7 +1824,7 @@ class Engine {
       err = amg_err;
       return amg_status;
     }
-    if (comm.active()) return comm.allgatherv(d_az, offs, stream, err);
+    if (comm.active()) return exchange_rows(d_az, err);
     return SIM3OPT_OK;
   }
 
@@ -1890,6 +1939,21 @@ class Engine {
       for (long long i = 0; i < h[255] && i < 255; ++i) std::fprintf(stderr, " %.1f", (h[i] - h[0]) * 0.01);
       std::fprintf(stderr, "\n");
     }
+    return SIM3OPT_OK;
+  }
+
+  // every rank's copy of `vec` gets the entries of the rows its own rows' blocks refer to: the boundary
+  // rows only (halo exchange) where the partition has locality, the whole vector otherwise
+  int exchange_rows(double* vec, std::string& err) {
+    if (!use_halo) return comm.allgatherv(vec, offs, stream, err);
+    const int k0 = halo_seg[comm.rank], k1 = halo_seg[comm.rank + 1];
+    if (k1 > k0)
+      hipLaunchKernelGGL(k_halo_pack, dim3((7 * (k1 - k0) + WG - 1) / WG), dim3(WG), 0, stream, k0, k1,
+                         (const int32_t*)d_brow, (const double*)vec, d_halo);
+    int rc = comm.allgatherv(d_halo, halo_offs, stream, err);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_halo_unpack, dim3((7 * n_halo + WG - 1) / WG), dim3(WG), 0, stream, n_halo, k0, k1,
+                       (const int32_t*)d_brow, (const double*)d_halo, vec);
     return SIM3OPT_OK;
   }
 
@@ -2116,7 +2180,7 @@ class Engine {
     }
     HIPCHK(hipGetLastError());
     if (multi && !use_mg) {  // (the multigrid cycle gathers its own operands)
-      rc = comm.allgatherv(d_z, offs, stream, err);
+      rc = exchange_rows(d_z, err);
       if (rc) return rc;
     }
     // (a multigrid iteration is ~1 ms of GPU work and its coarse launches run even after `done`:
@@ -2200,8 +2264,8 @@ class Engine {
           rc = amg_apply(err);
           if (rc) return rc;
         }
-        if (multi && !use_mg) {  // the next SpMV gathers z from every rank
-          rc = comm.allgatherv(d_z, offs, stream, err);
+        if (multi && !use_mg) {  // the next SpMV gathers z from the neighbouring ranks
+          rc = exchange_rows(d_z, err);
           if (rc) return rc;
         }
         par ^= 1;
@@ -2599,7 +2663,24 @@ int engine_bench_spmv_symmetric(Engine* e, int32_t reps, double out[4], std::str
   // reference: the product SpMV, q = H p
   e->spmv_raw(0.0, e->d_p, e->d_q, e->d_b, nullptr);
   const int g1 = (nb + 3) / 4, g2 = (7 * nb + WG - 1) / WG;
-  hipLaunchKernelGGL(k_symm_phase1, dim3(g1), dim3(WG), 0, st, nb, d_ur, d_uc, d_uv, e->d_p, d_y, d_t);
+  // variant 1 (SIM3OPT_SYMM_VARIANT=1, round 3): phase 1 with row spans, pipelining, shared gather and
+  // batched t stores (k_symm_phase1_span); its spans are balanced by the stored upper blocks
+  const bool span = std::getenv("SIM3OPT_SYMM_VARIANT") && std::atoi(std::getenv("SIM3OPT_SYMM_VARIANT")) == 1;
+  int gs = std::max(std::min(2048, (nb + 3) / 4), (nb + 15) / 16);
+  if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) gs = std::max(8, std::atoi(ev));
+  int32_t* d_uw = nullptr;
+  {
+    std::vector<int32_t> uw(gs * 4 + 1);
+    partition_rows(nb, urowptr.data(), gs * 4, uw.data());
+    if (dev_malloc((void**)&d_uw, sizeof(int32_t) * uw.size()) != hipSuccess) { cleanup(); err = "bench_spmv_symmetric: hipMalloc"; return SIM3OPT_ERR_HIP; }
+    tmp.push_back(d_uw);
+    (void)hipMemcpy(d_uw, uw.data(), sizeof(int32_t) * uw.size(), hipMemcpyHostToDevice);
+  }
+  auto phase1 = [&]() {
+    if (span) hipLaunchKernelGGL(k_symm_phase1_span, dim3(gs), dim3(WG), 0, st, nb, d_uw, d_ur, d_uc, d_uv, e->d_p, d_y, d_t);
+    else hipLaunchKernelGGL(k_symm_phase1, dim3(g1), dim3(WG), 0, st, nb, d_ur, d_uc, d_uv, e->d_p, d_y, d_t);
+  };
+  phase1();
   hipLaunchKernelGGL(k_symm_phase2, dim3(g2), dim3(WG), 0, st, 7 * nb, d_lp, d_li, d_t, d_y);
   std::vector<double> q((size_t)7 * nb), ys((size_t)7 * nb);
   (void)hipMemcpyAsync(q.data(), e->d_q, sizeof(double) * q.size(), hipMemcpyDeviceToHost, st);
@@ -2612,11 +2693,9 @@ int engine_bench_spmv_symmetric(Engine* e, int32_t reps, double out[4], std::str
   }
   out[2] = qmax > 0 ? dmax / qmax : dmax;
   float ms = 0.f;
-  for (int w = 0; w < 3; ++w)
-    hipLaunchKernelGGL(k_symm_phase1, dim3(g1), dim3(WG), 0, st, nb, d_ur, d_uc, d_uv, e->d_p, d_y, d_t);
+  for (int w = 0; w < 3; ++w) phase1();
   (void)hipEventRecord(e->ev_a, st);
-  for (int w = 0; w < reps; ++w)
-    hipLaunchKernelGGL(k_symm_phase1, dim3(g1), dim3(WG), 0, st, nb, d_ur, d_uc, d_uv, e->d_p, d_y, d_t);
+  for (int w = 0; w < reps; ++w) phase1();
   (void)hipEventRecord(e->ev_b, st);
   (void)hipEventSynchronize(e->ev_b);
   (void)hipEventElapsedTime(&ms, e->ev_a, e->ev_b);

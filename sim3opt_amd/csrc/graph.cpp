@@ -6,15 +6,32 @@
 
 namespace sim3opt {
 
-bool build_structure(const HostGraph& g, Structure& s, std::string& err) {
+bool build_structure(const HostGraph& g, Structure& s, std::string& err,
+                     const std::vector<int32_t>* row_order) {
   const int32_t nv = g.nv(), ne = g.ne();
   s = Structure();
   s.hidx.assign(nv, -1);
-  for (int32_t v = 0; v < nv; ++v)
-    if (!g.fixed[v]) {
+  if (row_order) {
+    for (int32_t v : *row_order) {
+      if (v < 0 || v >= nv || g.fixed[v] || s.hidx[v] >= 0) {
+        err = "row order: not a permutation of the free vertices";
+        return false;
+      }
       s.hidx[v] = s.nb++;
       s.row2vertex.push_back(v);
     }
+    for (int32_t v = 0; v < nv; ++v)
+      if (!g.fixed[v] && s.hidx[v] < 0) {
+        err = "row order: a free vertex is missing";
+        return false;
+      }
+  } else {
+    for (int32_t v = 0; v < nv; ++v)
+      if (!g.fixed[v]) {
+        s.hidx[v] = s.nb++;
+        s.row2vertex.push_back(v);
+      }
+  }
   if (s.nb == 0 || ne == 0) {
     err = "nothing to optimise: no free vertex or no edge";
     return false;
@@ -91,6 +108,87 @@ bool build_structure(const HostGraph& g, Structure& s, std::string& err) {
     }
   }
   return true;
+}
+
+void locality_order(const HostGraph& g, std::vector<int32_t>& order) {
+  const int32_t nv = g.nv(), ne = g.ne();
+  order.clear();
+  // adjacency among free vertices (CSR, duplicates from parallel edges are harmless)
+  std::vector<int32_t> ptr(nv + 1, 0);
+  for (int32_t k = 0; k < ne; ++k) {
+    const int32_t a = g.ev0[k], b = g.ev1[k];
+    if (a == b || g.fixed[a] || g.fixed[b]) continue;
+    ++ptr[a + 1];
+    ++ptr[b + 1];
+  }
+  for (int32_t v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+  std::vector<int32_t> nbr(ptr[nv]), fill(ptr.begin(), ptr.end() - 1);
+  for (int32_t k = 0; k < ne; ++k) {
+    const int32_t a = g.ev0[k], b = g.ev1[k];
+    if (a == b || g.fixed[a] || g.fixed[b]) continue;
+    nbr[fill[a]++] = b;
+    nbr[fill[b]++] = a;
+  }
+  auto degree = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
+  std::vector<int32_t> level(nv, -1), queue;
+  // breadth-first search from `root` over vertices with level < 0 or of the current sweep `mark`;
+  // returns the last vertex reached (a farthest one)
+  std::vector<int32_t> mark(nv, -1);
+  auto bfs = [&](int32_t root, int32_t sweep, std::vector<int32_t>* out) {
+    queue.clear();
+    queue.push_back(root);
+    mark[root] = sweep;
+    std::vector<int32_t> nb_sorted;
+    for (size_t head = 0; head < queue.size(); ++head) {
+      const int32_t v = queue[head];
+      nb_sorted.clear();
+      for (int32_t e = ptr[v]; e < ptr[v + 1]; ++e) {
+        const int32_t w = nbr[e];
+        if (mark[w] != sweep && level[w] < 0) {
+          mark[w] = sweep;
+          nb_sorted.push_back(w);
+        }
+      }
+      std::sort(nb_sorted.begin(), nb_sorted.end(), [&](int32_t x, int32_t y) {
+        const int32_t dx = degree(x), dy = degree(y);
+        return dx != dy ? dx < dy : x < y;
+      });
+      queue.insert(queue.end(), nb_sorted.begin(), nb_sorted.end());
+    }
+    if (out) *out = queue;
+    return queue.back();
+  };
+  int32_t sweep = 0;
+  for (int32_t v0 = 0; v0 < nv; ++v0) {
+    if (g.fixed[v0] || level[v0] >= 0) continue;
+    // pseudo-peripheral start of this component: twice to the far end
+    int32_t root = bfs(v0, sweep++, nullptr);
+    root = bfs(root, sweep++, nullptr);
+    std::vector<int32_t> comp;
+    bfs(root, sweep++, &comp);
+    for (int32_t v : comp) {
+      level[v] = 0;
+      order.push_back(v);
+    }
+  }
+}
+
+void boundary_rows(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int32_t world,
+                   const int32_t* row_begin, std::vector<int32_t>& rows, std::vector<int32_t>& seg) {
+  rows.clear();
+  seg.assign(world + 1, 0);
+  int32_t r = 0;
+  for (int32_t i = 0; i < nb; ++i) {
+    while (r + 1 < world && i >= row_begin[r + 1]) ++r;
+    bool cut = false;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1] && !cut; ++k)
+      cut = colidx[k] < row_begin[r] || colidx[k] >= row_begin[r + 1];
+    if (cut) {
+      rows.push_back(i);
+      ++seg[r + 1];
+    }
+  }
+  for (int32_t q = 0; q < world; ++q) seg[q + 1] += seg[q];
 }
 
 void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin) {

@@ -82,3 +82,100 @@ __global__ __launch_bounds__(WG) void k_symm_phase2(int n7, const int32_t* __res
   for (; m < m1; ++m) acc += tvec[(size_t)7 * lidx[m] + c];
   y[t] = acc;
 }
+
+// Round 3: phase 1 with the product kernel's machinery -- a contiguous span of rows per wavefront
+// (balanced by stored upper blocks), chunks of 8 blocks software-pipelined across row boundaries,
+// ONE shared gather of x per chunk (lane 7u + c reads x[7 col_u + c]), column indices 64 at a time --
+// and the t vectors of a chunk written by ONE store: after the xor butterfly every lane of the 8-lane
+// group c holds t_u(c), so lane (r, c) keeps the one of block u = r and the 56 lanes write the 448
+// contiguous bytes of the chunk's eight t vectors (diagonal blocks get a slot nobody reads).
+__global__ __launch_bounds__(WG) void k_symm_phase1_span(int nb, const int32_t* __restrict__ uwrow,
+                                                         const int32_t* __restrict__ urowptr,
+                                                         const int32_t* __restrict__ ucol,
+                                                         const double* __restrict__ uvals,
+                                                         const double* __restrict__ x, double* __restrict__ y,
+                                                         double* __restrict__ tvec) {
+  constexpr int CH = 8;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int r = lane & 7, c = lane >> 3;
+  const bool act = r < 7 && c < 7;
+  const int e = act ? r + 7 * c : 0;
+  const int cc = c < 7 ? c : 0, rr = r < 7 ? r : 0;
+  const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
+  const int rA = uwrow[w], rB = uwrow[w + 1];
+  if (rA >= rB) return;
+  const int kbeg = urowptr[rA], kend = urowptr[rB];
+  int rbase = rA;
+  int rpv = rbase + 1 + lane <= rB ? urowptr[rbase + 1 + lane] : kend;
+  int row = rA;
+  int k1 = __builtin_amdgcn_readlane(rpv, 0);
+  int cbase = kbeg;
+  int cv = cbase + lane < kend ? ucol[cbase + lane] : 0;
+  int cvn = cbase + 64 + lane < kend ? ucol[cbase + 64 + lane] : 0;
+  double vc[CH], vn[CH];
+  double xgc, xgn = 0.0;
+  auto load_chunk = [&](int ks, double* dst) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int kk = ks + u < kend ? ks + u : kend - 1;
+      dst[u] = __builtin_nontemporal_load(uvals + (size_t)49 * kk + e);
+    }
+  };
+  {
+    load_chunk(kbeg, vc);
+    const int kk = kbeg + gu < kend ? kbeg + gu : kend - 1;
+    xgc = x[(size_t)7 * __shfl(cv, kk - cbase) + gc];
+  }
+  double xi = __shfl(xgc, rr);  // a row starts with its diagonal block: its own entries of x
+  double acc = 0.0;
+  auto row_end = [&](int rw, double a) {
+    a += __shfl_xor(a, 8);
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    if (lane < 7) y[(size_t)7 * rw + lane] = a;
+  };
+  for (int k = kbeg; k < kend; k += CH) {
+    const int kn = k + CH;
+    if (kn < kend) {
+      if (kn - cbase >= 64) {
+        cbase += 64;
+        cv = cvn;
+        cvn = cbase + 64 + lane < kend ? ucol[cbase + 64 + lane] : 0;
+      }
+      load_chunk(kn, vn);
+      const int kk = kn + gu < kend ? kn + gu : kend - 1;
+      xgn = x[(size_t)7 * __shfl(cv, kk - cbase) + gc];
+    }
+    double tmine = 0.0;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int kk = k + u;
+      if (kk < kend) {
+        if (kk == k1) {  // the previous row is complete; this block is the next row's diagonal
+          row_end(row, acc);
+          acc = 0.0;
+          ++row;
+          if (row - rbase >= 64) {
+            rbase += 64;
+            rpv = rbase + 1 + lane <= rB ? urowptr[rbase + 1 + lane] : kend;
+          }
+          k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
+          xi = __shfl(xgc, 7 * u + rr);
+        }
+        const double av = act ? vc[u] : 0.0;
+        acc += av * __shfl(xgc, 7 * u + cc);
+        double tt = av * xi;
+        tt += __shfl_xor(tt, 1);
+        tt += __shfl_xor(tt, 2);
+        tt += __shfl_xor(tt, 4);
+        if (r == u) tmine = tt;
+      }
+    }
+    if (c < 7 && k + r < kend) tvec[(size_t)7 * (k + r) + c] = tmine;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) vc[u] = vn[u];
+    xgc = xgn;
+  }
+  row_end(row, acc);
+}

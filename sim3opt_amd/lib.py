@@ -141,6 +141,7 @@ SYMBOLS = {
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
+    "sim3opt_partition_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, C.POINTER(C.c_int64)]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
     "sim3opt_partition_rows_equal": (C.c_int, [C.c_int32, C.c_int32, _ip]),
     "sim3opt_load_kitti_direct": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
@@ -498,6 +499,19 @@ class Graph:
         self._chk(self._L.sim3opt_amg_hierarchy(self._g, 16, C.byref(nl), _p(rows, _ip),
                                                 blocks.ctypes.data_as(C.c_void_p), _p(agg, _ip)))
         return rows[:nl.value].copy(), blocks[:nl.value].copy(), agg
+
+    def partition_plan(self, world, locality=True):
+        """(vertex of every block row, row_begin, boundary rows per rank, cut edges); host only."""
+        nfree = C.c_int32()
+        nblk = C.c_int64()
+        self._chk(self._L.sim3opt_system_pattern(self._g, C.byref(nfree), C.byref(nblk), None, None))
+        v = np.empty(nfree.value, dtype=np.int32)
+        rb = np.empty(world + 1, dtype=np.int32)
+        bnd = np.empty(world, dtype=np.int32)
+        cut = C.c_int64()
+        self._chk(self._L.sim3opt_partition_plan(self._g, int(world), int(bool(locality)), _p(v, _ip), _p(rb, _ip),
+                                                 _p(bnd, _ip), C.byref(cut)))
+        return v, rb, bnd, cut.value
 
     def bench_spmv(self, reps=20):
         ms = C.c_double()

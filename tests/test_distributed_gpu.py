@@ -77,6 +77,9 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
     res = [np.load(out + f".{r}.npz") for r in range(world)]
     if prec == 2:
         monkeypatch.setenv(*COARSEST)
+    # (a partitioned graph numbers its block rows in locality order; the single-process run it is
+    # compared with does the same, so that both build the same multigrid hierarchy)
+    monkeypatch.setenv("SIM3OPT_ROW_ORDER", "bfs")
     g = _graph(prec)
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
@@ -112,7 +115,7 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
 def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     """The RCCL transport (dlopen, ncclCommInitRank, in-place ncclAllReduce, grouped in-place
     ncclBroadcast on the engine's stream) exercised with one rank: every collective of the
-    multi-GPU branch runs and must reproduce the plain single-GPU result bit for bit."""
+    multi-GPU branch runs and must reproduce the plain single-GPU result (block-Jacobi: bit for bit)."""
     import ctypes as C
     from sim3opt_amd import lib as L
     monkeypatch.setenv("SIM3OPT_FORCE_COMM", "1")
@@ -122,7 +125,10 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     uid = np.zeros(128, dtype=np.uint8)
     assert L.load().sim3opt_comm_unique_id(uid.ctypes.data_as(L._up)) == L.OK
     assert uid.any()
-    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec, time_kernels=1)
+    # (delta = 1e-6: with three multigrid levels the partitioned path applies level 1's first smoothing
+    # step in a kernel of its own, after the all-reduce -- another summation order, last-bit differences
+    # in the preconditioner -- and delta = 1e-9 Jacobians would amplify those to 1e-5 in chi2)
+    A = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec, time_kernels=1, fd_delta=1e-6)
     A.add_vertices(g["states"], g["fixed"])
     A.add_edges(g["v0"], g["v1"], g["meas"])
     A.comm_init_rccl(0, 1, uid)
@@ -137,16 +143,19 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     A.kernel_times(reset=True)
     assert A.comm_times()["n_allreduce"] == 0 and A.comm_times()["ms_allgather"] == 0
     monkeypatch.delenv("SIM3OPT_FORCE_COMM")
-    B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec)
+    B = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-10, preconditioner=prec, fd_delta=1e-6)
     B.add_vertices(g["states"], g["fixed"])
     B.add_edges(g["v0"], g["v1"], g["meas"])
     B.initialize()
     B.optimize(3)
     assert [s.trials for s in A.stats()] == [s.trials for s in B.stats()]
+    if prec != 2:  # the same kernels in the same order: bit for bit
+        assert [s.chi2_after for s in A.stats()] == [s.chi2_after for s in B.stats()]
+    # (multigrid: solves stopped at 1e-10 by two slightly different preconditioners)
     assert np.allclose([s.chi2_after for s in A.stats()], [s.chi2_after for s in B.stats()],
-                       rtol=1e-9)
+                       rtol=1e-6 if prec == 2 else 1e-9)
     from sim3opt_amd import synth
-    assert synth.rmse(A.get_vertices(), B.get_vertices()) < 1e-7
+    assert synth.rmse(A.get_vertices(), B.get_vertices()) < (2e-5 if prec == 2 else 1e-7)
 
 
 # ------------------------------------------------------------------ config 4: the 100k / 1M graph
@@ -167,19 +176,22 @@ def _worker_cfg3(rank, world, port, out):
     chi0 = G.chi2()
     n = G.optimize(3)
     st = G.stats()
+    _, _, bnd, cut = G.partition_plan(world)
     np.savez(out + f".{rank}.npz", pos=synth.positions(G.get_vertices()), scale=G.get_vertices()[:, 7],
-             chi0=chi0, n=n, rows=[lo, hi], prec=G.preconditioner_in_use(),
+             chi0=chi0, n=n, rows=[lo, hi], prec=G.preconditioner_in_use(), n_halo=int(bnd.sum()), cut_edges=cut,
              chi=[s.chi2_after for s in st], trials=[s.trials for s in st],
              pcg=[s.pcg_iters for s in st], rel=[s.pcg_rel_res for s in st],
              rmse_gt=synth.rmse(G.get_vertices(), g["gt"]), rmse_gt0=synth.rmse(g["states"], g["gt"]))
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_config4_full_size_graph_row_partitioned(tmp_path, world):
+def test_config4_full_size_graph_row_partitioned(tmp_path, monkeypatch, world):
     """BASELINE.json configs[3]: the 100k-vertex / 1M-edge Manhattan graph row-partitioned over 2 and 4
-    ranks (here: processes sharing the one GPU, host-staged collectives; the kernels, the partition
-    and the collective sequence are those of the RCCL path -- N > 1 on xGMI itself is unmeasured on
-    hardware).  Same property checks as the single-GPU config-3 test, plus rank agreement and the
+    ranks (here: processes sharing the one GPU -- the box allows six processes on its card, the test
+    runner included, so 8 ranks cannot run here; the plan for 8 is checked on the host in
+    test_host.py::test_locality_order_and_halo_of_the_row_partition --, host-staged collectives; the kernels, the partition, the halo exchange and the collective
+    sequence are those of the RCCL path -- N > 1 on xGMI itself is unmeasured on hardware).  Same
+    property checks as the single-GPU config-3 test, plus rank agreement, the halo plan and the
     single-process chi2 trace."""
     from sim3opt_amd import lib as L, synth
     out = str(tmp_path / "c")
@@ -202,9 +214,12 @@ def test_config4_full_size_graph_row_partitioned(tmp_path, world):
     assert chi[-1] < 0.2 * float(r0["chi0"])
     assert all(float(x) <= 1e-8 for x in r0["rel"]) and all(0 < int(k) < 400 for k in r0["pcg"])
     assert float(r0["rmse_gt"]) < float(r0["rmse_gt0"])
-    # against the single-process run of the same graph
+    # the partition has locality: a minority of the rows is exchanged, few edges are linearised twice
+    assert int(r0["n_halo"]) < 0.45 * nb and int(r0["cut_edges"]) < 0.15 * 1000000, (int(r0["n_halo"]), int(r0["cut_edges"]))
+    # against the single-process run of the same graph in the same row order
     synth.DRIFT_TARGET = 0.05
     g = synth.manhattan()
+    monkeypatch.setenv("SIM3OPT_ROW_ORDER", "bfs")
     G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])

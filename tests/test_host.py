@@ -152,6 +152,44 @@ def test_partition_rows_balances_blocks():
     assert beg[0] == 0 and beg[-1] == 1 and np.all(np.diff(beg) >= 0)
 
 
+def test_locality_order_and_halo_of_the_row_partition():
+    """The partitioned path numbers the block rows breadth-first from a pseudo-peripheral vertex, so
+    that contiguous rank spans are slabs of the graph: on a Manhattan world a minority of the rows
+    has a neighbour on another rank (what the per-iteration halo exchange sends) and few edges are
+    cut (what two ranks linearise) -- in insertion order, along the random walk, nearly all are."""
+    from sim3opt_amd import synth
+    g = synth.manhattan(20000, 200000, dims=(40, 40, 10))
+    G = L.Graph()
+    G.add_vertices(g["states"], g["fixed"])
+    G.add_edges(g["v0"], g["v1"], g["meas"])
+    nb = 19999
+    for world in (2, 4, 8):
+        v, rb, bnd, cut = G.partition_plan(world, locality=True)
+        v0, rb0, bnd0, cut0 = G.partition_plan(world, locality=False)
+        assert sorted(v) == sorted(v0) == list(np.where(g["fixed"] == 0)[0])  # a permutation of the free vertices
+        assert np.array_equal(v0, np.where(g["fixed"] == 0)[0])                 # insertion order is g2o's
+        assert np.array_equal(rb, rb0) and rb[0] == 0 and rb[-1] == nb
+        assert bnd.sum() < 0.6 * bnd0.sum() and cut < 0.35 * cut0, (world, bnd.sum(), bnd0.sum(), cut, cut0)
+        # the boundary list is exactly the rows with a cross-rank neighbour
+        row_of = -np.ones(len(g["fixed"]), dtype=np.int64)
+        row_of[v] = np.arange(nb)
+        a, b = row_of[g["v0"]], row_of[g["v1"]]
+        ok = (a >= 0) & (b >= 0)
+        ra, rbk = np.searchsorted(rb, a[ok], side="right") - 1, np.searchsorted(rb, b[ok], side="right") - 1
+        crossing = ra != rbk
+        assert cut == int(crossing.sum())
+        rows = np.unique(np.concatenate([a[ok][crossing], b[ok][crossing]]))
+        assert [int(((rows >= rb[r]) & (rows < rb[r + 1])).sum()) for r in range(world)] == list(bnd)
+    # one rank: nothing to exchange
+    assert G.partition_plan(1)[2].sum() == 0 and G.partition_plan(1)[3] == 0
+    # a graph in two components is ordered component by component
+    H = L.Graph()
+    H.add_vertices(np.tile(I8, (7, 1)), [1, 0, 0, 0, 0, 0, 0])
+    H.add_edges([0, 1, 4, 5], [1, 2, 5, 6], np.tile(I8, (4, 1)))
+    v = H.partition_plan(2)[0]
+    assert sorted(v) == [1, 2, 3, 4, 5, 6] and set(v[:2]) == {1, 2} or set(v[-2:]) == {1, 2}
+
+
 def test_allgather_plan_for_uneven_and_empty_ranks():
     """The multi-GPU exchange is ONE in-place equal-count ncclAllGather: the library's own predicate
     and buffer sizing (comm.hpp allgather_equal_plan, used by the RCCL transport and by the engine's
