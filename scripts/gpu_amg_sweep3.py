@@ -17,7 +17,7 @@ for cfg in configs:
     for kv in cfg.split():
         k, v = kv.split("="); os.environ["SIM3OPT_AMG_" + k] = v
     try:
-        G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8, time_kernels=1)
+        G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8, time_kernels=1, preconditioner=int(os.environ.get("PREC", "-1")))
         G.add_vertices(g["states"], g["fixed"]); G.add_edges(g["v0"], g["v1"], g["meas"]); G.initialize()
         G.optimize(NWARM); G.set_vertices(g["states"])
         t = time.perf_counter(); G.optimize(NIT); dt = time.perf_counter() - t

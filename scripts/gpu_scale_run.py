@@ -20,4 +20,4 @@ out = dict(vertices=V, edges=E, preconditioner=G.preconditioner_in_use(), pcg_re
            chi2=[chi0] + [s.chi2_after for s in st], pcg_iters=[s.pcg_iters for s in st], ms_linearize=[s.ms_linearize for s in st],
            spmv_ms=kt.ms_spmv / max(kt.n_spmv, 1), spmv_GBs=byt / (kt.ms_spmv / max(kt.n_spmv, 1)) / 1e6, b2b_spmv_ms=G.bench_spmv(20))
 print(json.dumps(out))
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r1_scale_1M_10M_pre%d.json" % G.preconditioner_in_use()), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "scale_1M_10M_pre%d.json" % G.preconditioner_in_use())), "w"), indent=1)

@@ -4,7 +4,7 @@ TAG=${1:-bench}
 shift
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o $TAG -- python3 bench.py --main-only --no-cpu-baseline "$@" > gpurun_out/prof_bench_$TAG.log 2>&1
-tail -1 gpurun_out/prof_bench_$TAG.log > gpurun_out/prof_bench_${TAG}_line.json
+grep -m1 "^{\"metric\"" gpurun_out/prof_bench_$TAG.log > gpurun_out/prof_bench_${TAG}_line.json
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/prof_bench/${TAG}_kernel_stats.csv")))

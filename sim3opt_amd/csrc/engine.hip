@@ -77,6 +77,7 @@ struct DevScalars {
   double gam_last;   // r.z seen by the last executed step (reported relative residual)
   double lambda;     // damping of the current solve (read by the captured PCG launches)
   long long n_spmv_work;  // PCG SpMV launches that did their work (launches after `done` return at once)
+  double trace;           // sum of the scalar diagonal of H (mean |H_dd|: when is a system damping-dominated?)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -382,14 +383,16 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
                                                     const int32_t* __restrict__ rowptr,
                                                     const double* __restrict__ scratch,
                                                     double* __restrict__ vals,
-                                                    double* __restrict__ b, DevScalars* sc) {
+                                                    double* __restrict__ b, DevScalars* sc,
+                                                    double* __restrict__ trace_partials) {
+  __shared__ double sh[4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane % 7, c = lane / 7;
   const int m = r < c ? r : c, M = r < c ? c : r;
   const int tsrc = lane < 49 ? (M * (M + 1)) / 2 + m : 0;
   const int bsrc = lane < 7 ? 28 + lane : 0;
-  double dmax = 0.0;
+  double dmax = 0.0, tr = 0.0;
   for (int row = r0 + blockIdx.x * 4 + wave; row < r1; row += gridDim.x * 4) {
     const int k0 = incptr[row], k1 = incptr[row + 1];
     double sum = 0.0;
@@ -399,7 +402,10 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
     const double bv = __shfl(sum, bsrc);
     if (lane < 49) {
       vals[(size_t)49 * rowptr[row] + lane] = v;
-      if (r == c) dmax = fmax(dmax, fabs(v));
+      if (r == c) {
+        dmax = fmax(dmax, fabs(v));
+        tr += v;
+      }
     }
     if (lane < 7) b[(size_t)7 * row + lane] = bv;
   }
@@ -407,6 +413,8 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
   for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
   if (lane == 0 && dmax > 0.0)
     atomicMax(&sc->maxdiag_bits, (unsigned long long)__double_as_longlong(dmax));
+  const double ts = block_sum(tr, sh);  // fixed order: deterministic
+  if (threadIdx.x == 0) trace_partials[blockIdx.x] = ts;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1012,13 +1020,13 @@ __global__ __launch_bounds__(WG) void k_halo_pack(int k0, int k1, const int32_t*
                                                   const double* __restrict__ vec, double* __restrict__ buf) {
   const int t = blockIdx.x * WG + threadIdx.x;
   const int k = k0 + t / 7, c = t % 7;
-  if (k < k1) buf[(size_t)7 * k + c] = vec[(size_t)7 * brow[k] + c];
+  if (k < k1 && brow[k] >= 0) buf[(size_t)7 * k + c] = vec[(size_t)7 * brow[k] + c];
 }
 __global__ __launch_bounds__(WG) void k_halo_unpack(int n, int own0, int own1, const int32_t* __restrict__ brow,
                                                     const double* __restrict__ buf, double* __restrict__ vec) {
   const int t = blockIdx.x * WG + threadIdx.x;
   const int k = t / 7, c = t % 7;
-  if (k < n && (k < own0 || k >= own1)) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
+  if (k < n && (k < own0 || k >= own1) && brow[k] >= 0) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
 }
 
 // computeScale: sum_j x_j (lambda x_j + b_j)
@@ -1157,6 +1165,20 @@ class Engine {
   bool amg_over_on = true;             // cleared when an over-corrected cycle made the PCG break down
   int amg_pivot = 14;                  // pivot block of the dense coarsest inverse (14 or 28 rows: the same
                                        // total time -- the in-wavefront pivot inverse is what costs)
+  // Damping-dominated systems (round 3): when lambda is of the order of the diagonal of H -- the LM
+  // trials at the noise floor of the delta = 1e-9 Jacobians, lambda 2e2 ... 8e3 on config 3 -- plain
+  // block-Jacobi PCG converges in 3-11 iterations of 0.2 ms, while a multigrid solve pays 2 ms for the
+  // dense coarsest inverse plus 0.75 ms per iteration (measured from the same states and lambdas: 1.0-8.6
+  // ms against 7.5-35 ms per LM iteration, chi2 equal to the last digit; scripts/gpu_easy_solves.py).  A
+  // solve with lambda >= bj_gate therefore starts with block-Jacobi; after 8 iterations the observed
+  // reduction says how many it would need, and beyond `bj_budget` the solve starts again with the
+  // hierarchy.  The gate follows the outcomes (deterministic: same decisions in every run).
+  bool adaptive_prec = true;
+  double bj_gate = -1.0;   // lambda from which block-Jacobi is tried first (< 0: 0.05 x mean |H_dd|)
+  int bj_budget = 48;      // predicted iterations above which the probe is abandoned
+  int n_bj_solves = 0, n_bj_abandoned = 0;
+  bool trace_stale = true;
+  double mean_diag = 0.0;
   int amg_status = 0;                  // first collective error inside a cycle
   std::string amg_err;
   // exact sparse block Cholesky (direct.hpp, direct_kernels.hpp): LinearSolverEigen's role on
@@ -1185,7 +1207,7 @@ class Engine {
   // halo exchange (world > 1): boundary rows of all ranks, grouped by owner; this rank's share is
   // [halo_seg[rank], halo_seg[rank + 1]); halo_offs = 7 * halo_seg (doubles)
   bool use_halo = false;
-  int32_t n_halo = 0;
+  int32_t n_halo = 0, halo_slots = 0;  // boundary rows in all; slots per rank in the exchange buffer
   std::vector<int32_t> halo_seg;
   std::vector<int64_t> halo_offs;
   int32_t* d_brow = nullptr;
@@ -1260,19 +1282,26 @@ class Engine {
     offs.resize(comm.world + 1);
     for (int r = 0; r <= comm.world; ++r) offs[r] = 7 * (int64_t)row_begin[r];
     if (comm.world > 1 && !std::getenv("SIM3OPT_NO_HALO")) {
-      std::vector<int32_t> brow;
-      boundary_rows(nb, s.rowptr.data(), s.colidx.data(), comm.world, row_begin.data(), brow, halo_seg);
-      n_halo = (int32_t)brow.size();
+      std::vector<int32_t> brow_list;
+      boundary_rows(nb, s.rowptr.data(), s.colidx.data(), comm.world, row_begin.data(), brow_list, halo_seg);
+      n_halo = (int32_t)brow_list.size();
+      // every rank's segment of the exchange buffer has the same length (the largest boundary, short
+      // ones padded with -1): the exchange is then ONE in-place ncclAllGather, like the whole-vector one
+      halo_slots = 0;
+      for (int r = 0; r < comm.world; ++r) halo_slots = std::max(halo_slots, halo_seg[r + 1] - halo_seg[r]);
       halo_offs.resize(comm.world + 1);
-      for (int r = 0; r <= comm.world; ++r) halo_offs[r] = 7 * (int64_t)halo_seg[r];
+      for (int r = 0; r <= comm.world; ++r) halo_offs[r] = 7 * (int64_t)halo_slots * r;
       // (worth it while the boundary is a fraction of the vector; a partition in insertion order of a
       // graph without locality has nearly every row on it: the plain all-gather is cheaper then)
-      use_halo = n_halo > 0 && (int64_t)n_halo * 2 < nb;
+      use_halo = n_halo > 0 && (int64_t)halo_slots * comm.world * 2 < nb;
       if (use_halo) {
-        HIPCHK(upload(d_brow, brow));
-        int64_t padded = 0;
-        (void)allgather_equal_plan(halo_offs.data(), comm.world, nullptr, &padded);
-        HIPCHK(dev_malloc((void**)&d_halo, sizeof(double) * (size_t)std::max<int64_t>(padded, 7 * (int64_t)n_halo)));
+        std::vector<int32_t> padded((size_t)halo_slots * comm.world, -1);
+        for (int r = 0; r < comm.world; ++r)
+          std::copy(brow_list.begin() + halo_seg[r], brow_list.begin() + halo_seg[r + 1],
+                    padded.begin() + (size_t)halo_slots * r);
+        HIPCHK(upload(d_brow, padded));
+        HIPCHK(dev_malloc((void**)&d_halo, sizeof(double) * 7 * padded.size()));
+        HIPCHK(hipMemset(d_halo, 0, sizeof(double) * 7 * padded.size()));
       }
       if (opt.verbose)
         std::fprintf(stderr, "sim3opt: rank %d of %d: rows [%d, %d) of %d, %d boundary rows in all (%.1f %%): %s\n",
@@ -1514,6 +1543,8 @@ class Engine {
     }
     if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) amg_additive = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("SIM3OPT_AMG_FP32")) amg_fp32 = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("SIM3OPT_ADAPTIVE_PREC")) adaptive_prec = std::atoi(ev) != 0;
+    if (!automatic) adaptive_prec = false;  // (a caller who names the multigrid gets the multigrid)
     if (const char* ev = std::getenv("SIM3OPT_AMG_PIVOT")) amg_pivot = std::atoi(ev) >= 28 ? 28 : 14;
     // measured on config 3: 1.8 into level 0 and 1.6 below cut the PCG iterations of
     // a solve from 56 to 43 (cycle 1/3) and from 29 to 25 (cycle 2/3); 2.0 (the limit for an exact
@@ -1946,13 +1977,12 @@ class Engine {
   // rows only (halo exchange) where the partition has locality, the whole vector otherwise
   int exchange_rows(double* vec, std::string& err) {
     if (!use_halo) return comm.allgatherv(vec, offs, stream, err);
-    const int k0 = halo_seg[comm.rank], k1 = halo_seg[comm.rank + 1];
-    if (k1 > k0)
-      hipLaunchKernelGGL(k_halo_pack, dim3((7 * (k1 - k0) + WG - 1) / WG), dim3(WG), 0, stream, k0, k1,
-                         (const int32_t*)d_brow, (const double*)vec, d_halo);
+    const int k0 = halo_slots * comm.rank, k1 = k0 + halo_slots, nslots = halo_slots * comm.world;
+    hipLaunchKernelGGL(k_halo_pack, dim3((7 * halo_slots + WG - 1) / WG), dim3(WG), 0, stream, k0, k1,
+                       (const int32_t*)d_brow, (const double*)vec, d_halo);
     int rc = comm.allgatherv(d_halo, halo_offs, stream, err);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_halo_unpack, dim3((7 * n_halo + WG - 1) / WG), dim3(WG), 0, stream, n_halo, k0, k1,
+    hipLaunchKernelGGL(k_halo_unpack, dim3((7 * nslots + WG - 1) / WG), dim3(WG), 0, stream, nslots, k0, k1,
                        (const int32_t*)d_brow, (const double*)d_halo, vec);
     return SIM3OPT_OK;
   }
@@ -1992,11 +2022,15 @@ class Engine {
       else
         hipLaunchKernelGGL((k_linearize_numeric<false, false>), dim3(g), dim3(WG), 0, stream, A);
     }
-    hipLaunchKernelGGL(k_diag_reduce, dim3(grid_for(r1 - r0, 4)), dim3(WG), 0, stream, r0, r1,
-                       d_incptr, d_rowptr, d_scratch, d_vals, d_b, d_sc);
+    const int gdr = grid_for(r1 - r0, 4);
+    hipLaunchKernelGGL(k_diag_reduce, dim3(gdr), dim3(WG), 0, stream, r0, r1,
+                       d_incptr, d_rowptr, d_scratch, d_vals, d_b, d_sc, d_part_a);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gdr, &d_sc->trace);
     HIPCHK(hipGetLastError());
     if (comm.active()) {  // non-negative doubles order like their bit patterns
       int rc = comm.allreduce(reinterpret_cast<double*>(&d_sc->maxdiag_bits), 1, 1, stream, err);
+      if (rc) return rc;
+      rc = comm.allreduce(&d_sc->trace, 1, 0, stream, err);  // (every rank must take the same decisions)
       if (rc) return rc;
     }
     if (use_direct) {  // the factorisation's starting blocks: H in the layout of L, b permuted
@@ -2008,6 +2042,7 @@ class Engine {
     }
     linearized = true;
     amg_stale = true;
+    trace_stale = true;
     kt.n_linearize += 1;
     return SIM3OPT_OK;
   }
@@ -2071,6 +2106,32 @@ class Engine {
       *ok = true;
       return direct_solve(lambda, err);
     }
+    if (use_amg && adaptive_prec) {
+      // damping-dominated system?  (see adaptive_prec above)
+      if (trace_stale) {
+        int rc = fetch_scalars(err);
+        if (rc) return rc;
+        mean_diag = n > 0 ? h_sc->trace / (double)n : 0.0;
+        trace_stale = false;
+      }
+      const double gate = bj_gate >= 0.0 ? bj_gate : 0.05 * mean_diag;
+      if (mean_diag > 0.0 && lambda >= gate) {
+        bool abandoned = false;
+        int rc = pcg_attempt(lambda, 0, iters, rel_res, ok, nullptr, err, bj_budget, &abandoned);
+        if (rc) return rc;
+        if (opt.verbose >= 2)
+          std::fprintf(stderr, "  lambda %.3g >= %.3g (mean |H_dd| %.3g): block-Jacobi first: %s after %d iterations\n",
+                       lambda, gate, mean_diag, abandoned ? "abandoned" : "done", *iters);
+        if (!abandoned) {
+          ++n_bj_solves;
+          if (*ok && *iters <= bj_budget / 4) bj_gate = std::min(gate, 0.5 * lambda);
+          else bj_gate = std::min(gate, lambda);
+          return SIM3OPT_OK;
+        }
+        ++n_bj_abandoned;
+        bj_gate = 2.0 * lambda;  // not before the damping has doubled
+      }
+    }
     if (use_amg || use_chain) {
       // the block-tridiagonal factorisation (or the multigrid's coarsest-level inverse) can meet a
       // non-positive pivot when H is numerically semi-definite (cond ~1e12 in the reference's
@@ -2102,9 +2163,13 @@ class Engine {
   }
 
   // prec: 0 block-Jacobi, 1 chain segments, 2 aggregation multigrid
+  // probe_budget > 0 (block-Jacobi tried first on a damping-dominated system): after 8 iterations the
+  // reduction reached so far predicts the total; if that exceeds the budget -- or the budget runs out --
+  // *abandoned is set and the caller solves again with the hierarchy
   int pcg_attempt(double lambda, int prec, int32_t* iters, double* rel_res, bool* ok,
-                  bool* chain_broke, std::string& err) {
+                  bool* chain_broke, std::string& err, int probe_budget = 0, bool* abandoned = nullptr) {
     const bool use_chain = prec == 1, use_mg = prec == 2;
+    const bool probe = probe_budget > 0;
     double* const zin = use_mg ? d_az : d_z;  // preconditioned residual the PCG consumes
     // r.z: from the SpMV's own pass over r -- or, with the multiplicative multigrid cycle, from the
     // cycle's last kernel, which holds r and writes z (the SpMV then skips its load of r)
@@ -2120,8 +2185,9 @@ class Engine {
     const double* scal = pre_sum ? &d_sc->tmp_pq : nullptr;
     // automatic cap: small systems may need ~n iterations for an (almost) exact step like the
     // reference's Cholesky (chains are ill-conditioned); large ones get a truncated-Newton budget
-    const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters
-                                             : (n <= 50000 ? std::max(100, 2 * n) : 1000);
+    int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters
+                                       : (n <= 50000 ? std::max(100, 2 * n) : 1000);
+    if (probe) max_it = std::min(max_it, probe_budget);
     const int nseg = (nloc + chain_seg - 1) / chain_seg;
     const int gc = grid_for(nseg, 4);  // chain apply: one wavefront per segment
     const double* Minv_arg = use_chain ? nullptr : d_Minv;
@@ -2185,13 +2251,14 @@ class Engine {
     }
     // (a multigrid iteration is ~1 ms of GPU work and its coarse launches run even after `done`:
     // poll more often)
-    const int chunk = use_mg ? std::min(4, std::max(1, opt.pcg_check_every)) : std::max(1, opt.pcg_check_every);
+    const int chunk = use_mg ? std::min(4, std::max(1, opt.pcg_check_every))
+                             : (probe ? 8 : std::max(1, opt.pcg_check_every));
     int it = 0, par = 0;
     // Launch-bound regime (small graphs: two ~3 us kernels per iteration): replay a captured
     // hipGraph of PCG_GRAPH_ITERS iterations instead of enqueueing them one by one.  The first
     // iteration stays eager (it carries it == 0); captured steps read the counter, the damping and
     // the stopping state from DevScalars, so one instantiated graph serves every solve.
-    const bool graphed = !multi && !opt.time_kernels && opt.pcg_graph && max_it > PCG_GRAPH_ITERS;
+    const bool graphed = !multi && !opt.time_kernels && opt.pcg_graph && max_it > PCG_GRAPH_ITERS && !probe;
     if (graphed && (!pcg_graph || pcg_graph_kind != prec)) {
       if (pcg_graph) { (void)hipGraphExecDestroy(pcg_graph); pcg_graph = nullptr; }
       // a multigrid iteration is ~20 launches: shorter graphs waste fewer no-op launches after
@@ -2235,6 +2302,12 @@ class Engine {
         spmv_work_seen = h_sc->n_spmv_work;
       }
       if (h_sc->done || h_sc->stop || h_sc->fail || it >= max_it) break;
+      if (probe && it >= 8 && h_sc->rz0 > 0.0) {
+        // squared M^-1-norm reduction after `it` iterations -> iterations to the tolerance at that rate
+        const double ratio = std::fabs(h_sc->gam_last) / h_sc->rz0;
+        const double need = ratio > 0.0 && ratio < 1.0 ? it * std::log(h_sc->tol2) / std::log(ratio) : 1e30;
+        if (need > probe_budget) break;
+      }
       if (graphed && it > 0 && par == 1 && max_it - it >= graph_iters) {
         // steps past max_iter cannot happen: the step that reaches it raises `stop`, and the
         // following launches of the replay are no-ops
@@ -2272,6 +2345,14 @@ class Engine {
         ++it;
       }
       HIPCHK(hipGetLastError());
+    }
+    if (probe && abandoned && !h_sc->done && !h_sc->fail) {  // (ran out of budget or predicted to)
+      *abandoned = true;
+      kt.n_pcg_vec += h_sc->iter;
+      *iters = h_sc->iter;
+      *rel_res = h_sc->rz0 > 0 ? std::sqrt(std::fabs(h_sc->gam_last) / h_sc->rz0) : 0.0;
+      *ok = true;
+      return SIM3OPT_OK;
     }
     if (multi) {  // every rank updates its replica of all estimates
       rc = comm.allgatherv(d_x, offs, stream, err);

@@ -89,6 +89,24 @@ __global__ __launch_bounds__(WG) void k_symm_phase2(int n7, const int32_t* __res
 // and the t vectors of a chunk written by ONE store: after the xor butterfly every lane of the 8-lane
 // group c holds t_u(c), so lane (r, c) keeps the one of block u = r and the 56 lanes write the 448
 // contiguous bytes of the chunk's eight t vectors (diagonal blocks get a slot nobody reads).
+// lane exchange inside rows of 16 lanes on the VALU (DPP) instead of the LDS crossbar: the three xor
+// steps per block of the t reduction made the first span version LDS-instruction-bound (it took
+// the time of the naive one)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes r = 0..7 of a group (all 8 get it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ double sum8_dpp(double t) {
+  t += dpp_f64<0xB1>(t);
+  t += dpp_f64<0x4E>(t);
+  t += dpp_f64<0x141>(t);
+  return t;
+}
+
 __global__ __launch_bounds__(WG) void k_symm_phase1_span(int nb, const int32_t* __restrict__ uwrow,
                                                          const int32_t* __restrict__ urowptr,
                                                          const int32_t* __restrict__ ucol,
@@ -165,10 +183,7 @@ __global__ __launch_bounds__(WG) void k_symm_phase1_span(int nb, const int32_t* 
         }
         const double av = act ? vc[u] : 0.0;
         acc += av * __shfl(xgc, 7 * u + cc);
-        double tt = av * xi;
-        tt += __shfl_xor(tt, 1);
-        tt += __shfl_xor(tt, 2);
-        tt += __shfl_xor(tt, 4);
+        const double tt = sum8_dpp(av * xi);
         if (r == u) tmine = tt;
       }
     }

@@ -264,7 +264,10 @@ def test_multigrid_preconditioner_solution_and_iterations(monkeypatch):
             res[(tag, lam)] = (x, it)
     for lam in (10.0, 1e-2):
         xb, itb = res[("bj", lam)]
-        assert res[("auto", lam)][1] == res[("default", lam)][1]  # >= 2000 loop-rich rows: automatic
+        # >= 2000 loop-rich rows: the automatic choice is the hierarchy -- except that a damping-dominated
+        # solve (lambda of the order of the diagonal of H: here 10) starts with block-Jacobi, which
+        # finishes it (round 3, Engine::adaptive_prec)
+        assert res[("auto", lam)][1] == res[("default" if lam < 1 else "bj", lam)][1]
         for tag in ("default", "w", "v", "add"):
             x, it = res[(tag, lam)]
             assert np.abs(x - xb).max() < 1e-6 * np.abs(xb).max()
