@@ -556,6 +556,32 @@ def test_multigrid_in_the_reference_arithmetic_matches_oracle():
         lam = t.lambda_
 
 
+def test_damping_dominated_solves_start_with_block_jacobi(monkeypatch):
+    """Engine::adaptive_prec (round 3): with the automatic preconditioner a solve whose lambda is of the
+    order of the diagonal of H starts with block-Jacobi (a few cheap iterations instead of a multigrid
+    set-up); the rule changes which preconditioner runs, never what is solved: the LM trace with the
+    rule equals the trace without it, and a lightly damped run never takes the shortcut."""
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(3000, 30000, dims=(17, 17, 10))
+    runs = {}
+    for tag, adaptive, lam0 in (("on", "1", 50.0), ("off", "0", 50.0), ("on_light", "1", 0.0), ("off_light", "0", 0.0)):
+        monkeypatch.setenv("SIM3OPT_ADAPTIVE_PREC", adaptive)
+        G = mk(g, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, user_lambda_init=lam0)
+        assert G.preconditioner_in_use() == 2
+        assert G.optimize(4) == 4
+        runs[tag] = ([s.chi2_after for s in G.stats()], [s.pcg_iters for s in G.stats()],
+                     [s.trials for s in G.stats()], G.get_vertices(), [s.pcg_rel_res for s in G.stats()])
+    for a, b in (("on", "off"), ("on_light", "off_light")):
+        assert runs[a][2] == runs[b][2]
+        assert np.allclose(runs[a][0], runs[b][0], rtol=1e-9, atol=0)
+        assert synth.rmse(runs[a][3], runs[b][3]) < 1e-7
+        assert max(runs[a][4]) <= 1e-12
+    # heavily damped (lambda_0 = 50 against mean |H_dd| of a few hundred): other iteration counts, i.e.
+    # the other preconditioner ran; lightly damped (g2o's lambda_0 = 1e-5 max |H_dd|): the same solves
+    assert runs["on"][1] != runs["off"][1]
+    assert runs["on_light"][1] == runs["off_light"][1]
+
+
 def test_huber_and_information_lm_through_multigrid():
     """Robust weights and dense information matrices only change the numbers of H: the multigrid
     hierarchy (Galerkin products of whatever the linearisation wrote) must follow."""
