@@ -8,7 +8,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := sim3opt_amd/csrc
 # one list of translation units, shared with sim3opt_amd/build.py
 SRCS  := $(addprefix $(CSRC)/,$(shell cat $(CSRC)/SOURCES))
-HDRS  := $(wildcard $(CSRC)/*.hpp) include/sim3opt.h $(CSRC)/SOURCES
+HDRS  := $(wildcard $(CSRC)/*.hpp) include/sim3opt.h include/sim3opt_bench.h $(CSRC)/SOURCES
 LIB   ?= sim3opt_amd/libsim3opt.so
 LIBDIR = $(abspath $(dir $(LIB)))
 EIGEN_INC ?= -Itests/mock_eigen

@@ -496,9 +496,15 @@ def main():
                 "fix_small_angle_b": 0, "steps": rdone, "value": rdone / rdt, "unit": "LM iter/s",
                 "chi2_initial": r0, "chi2_final": R.chi2(),
                 "pcg_iters": [int(s.pcg_iters) for s in rstats],
+                "lm_trials": [int(s.trials) for s in rstats],
+                "pcg_rel_res": [float("%.2e" % s.pcg_rel_res) for s in rstats],
+                "preconditioner": {0: "block-Jacobi", 1: "chain-segment", 2: "aggregation-multigrid"}[R.preconditioner_in_use()],
                 "lambda_last": rstats[-1].lambda_ if rstats else None,
                 "note": "B coefficient as written in sim3_rv.h:166/:290: lambda_0 = 1e-5 * max|H_dd| "
-                        "is ~1e8 and LM barely moves (DESIGN.md)"}
+                        "is ~1e8 and LM barely moves (DESIGN.md); since round 3 the multigrid hierarchy "
+                        "is automatic here too and the solves converge (pcg_rel_res: last trial of each "
+                        "iteration; a trial whose system is not numerically positive definite is "
+                        "rejected like g2o's failed Cholesky)"}
             R.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, out["ms_linearize_mean"], out["value"])

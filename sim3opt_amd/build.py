@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libsim3opt.so")
 # the one list of translation units, shared with the Makefile
 SOURCES = open(os.path.join(CSRC, "SOURCES")).read().split()
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [
-    os.path.join("..", "..", "include", "sim3opt.h"), "SOURCES"]
+    os.path.join("..", "..", "include", "sim3opt.h"), os.path.join("..", "..", "include", "sim3opt_bench.h"), "SOURCES"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-result"]

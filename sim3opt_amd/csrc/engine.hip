@@ -80,1022 +80,12 @@ struct DevScalars {
   double trace;           // sum of the scalar diagonal of H (mean |H_dd|: when is a system damping-dominated?)
 };
 
-// ------------------------------------------------------------------------------------------
-// reductions (fixed order => deterministic)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
-__device__ __forceinline__ double block_sum(double v, double* sh4) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
-}
-
-__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n, double* sh4) {
-  // (four loads in flight per thread: with thousands of partials the plain loop was a chain of
-  // load-wait-add round trips)
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * WG < n; i += 4 * WG) {
-    const double v0 = p[i], v1 = p[i + WG], v2 = p[i + 2 * WG], v3 = p[i + 3 * WG];
-    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-  }
-  for (; i < n; i += WG) a0 += p[i];
-  return block_sum((a0 + a1) + (a2 + a3), sh4);
-}
-
-__global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ partials, int n,
-                                                  double* __restrict__ out) {
-  __shared__ double sh[4];
-  const double s = sum_partials(partials, n, sh);
-  if (threadIdx.x == 0) *out = s;
-}
-
-// two sums in one launch (multi-GPU PCG: [w.z, r.z] land in adjacent doubles for one all-reduce)
-__global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa,
-                                                   const double* __restrict__ pb, int n,
-                                                   double* __restrict__ out2) {
-  __shared__ double sh[4];
-  const double a = sum_partials(pa, n, sh);
-  const double b = sum_partials(pb, n, sh);
-  if (threadIdx.x == 0) {
-    out2[0] = a;
-    out2[1] = b;
-  }
-}
-
-// multi-GPU: the breakdown flag is rank-local (a non-SPD block on one rank's rows); the ranks agree
-// on it through a max all-reduce of tmp_pq so that they keep taking the same branches
-__global__ void k_fail_to_double(DevScalars* sc) { sc->tmp_pq = sc->fail ? 1.0 : 0.0; }
-__global__ void k_double_to_fail(DevScalars* sc) { if (sc->tmp_pq > 0.0) sc->fail = 1; }
-
-// ------------------------------------------------------------------------------------------
-// per-edge residual kernels
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ Sim3 load_sim3(const Sim3* __restrict__ p) {
-  Sim3 s;
-  const double* d = reinterpret_cast<const double*>(p);
-  s.q[0] = d[0]; s.q[1] = d[1]; s.q[2] = d[2]; s.q[3] = d[3];
-  s.t[0] = d[4]; s.t[1] = d[5]; s.t[2] = d[6]; s.s = d[7];
-  return s;
-}
-
-__device__ __forceinline__ double quad_form(const double e[7], const double* __restrict__ Om) {
-  double acc = 0.0;
-#pragma unroll
-  for (int c = 0; c < 7; ++c) {
-    double col = 0.0;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) col += e[r] * Om[7 * c + r];
-    acc += col * e[c];
-  }
-  return acc;
-}
-
-// g2o RobustKernelHuber: rho(e2) and rho'(e2)
-__device__ __forceinline__ void huber(double e2, double delta, double& rho, double& w) {
-  const double dsqr = delta * delta;
-  if (e2 <= dsqr) {
-    rho = e2;
-    w = 1.0;
-  } else {
-    const double sq = sqrt(e2);
-    rho = 2 * sq * delta - dsqr;
-    w = delta / sq;
-  }
-}
-
-// FP32 copies of the blocks (multigrid matrix passes) are stored as interleaved PAIRS: entry e of
-// block k sits at 98 (k / 2) + 2 e + (k mod 2), so that ONE 8-byte load per lane brings the same entry
-// of two consecutive blocks -- 392 bytes per wavefront instruction, like an FP64 block, instead of 196.
-__host__ __device__ __forceinline__ size_t f32_pair_index(int64_t k, int e) {
-  return (size_t)98 * (size_t)(k >> 1) + (size_t)(2 * e) + (size_t)(k & 1);
-}
-
-struct EdgeArgs {
-  int32_t e_lo, e_hi;  // edge range evaluated by this launch (rank's share in multi-GPU chi2)
-  const int32_t* ev0;
-  const int32_t* ev1;
-  const Sim3* meas;
-  const double* info;    // nullptr: identity
-  const double* kdelta;  // nullptr: no robust kernel
-  const Sim3* states;
-  sim3::Opts opts;
-};
-
-// computeActiveErrors + activeRobustChi2: one lane per edge, block partials in fixed order.
-__global__ __launch_bounds__(WG) void k_chi2(EdgeArgs A, double* __restrict__ partials) {
-  __shared__ double sh[4];
-  double acc = 0.0;
-  for (int k = A.e_lo + blockIdx.x * WG + threadIdx.x; k < A.e_hi; k += gridDim.x * WG) {
-    const Sim3 C = load_sim3(A.meas + k);
-    const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
-    const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
-    double e[7];
-    sim3::edge_error(C, S0, S1, A.opts, e);
-    double chi;
-    if (A.info) {
-      chi = quad_form(e, A.info + (size_t)49 * k);
-    } else {
-      chi = 0.0;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) chi += e[r] * e[r];
-    }
-    if (A.kdelta && A.kdelta[k] > 0.0) {
-      double rho, w;
-      huber(chi, A.kdelta[k], rho, w);
-      chi = rho;
-    }
-    acc += chi;
-  }
-  const double s = block_sum(acc, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
-__global__ __launch_bounds__(WG) void k_edge_errors(EdgeArgs A, double* __restrict__ out) {
-  for (int k = A.e_lo + blockIdx.x * WG + threadIdx.x; k < A.e_hi; k += gridDim.x * WG) {
-    const Sim3 C = load_sim3(A.meas + k);
-    const Sim3 S0 = load_sim3(A.states + A.ev0[k]);
-    const Sim3 S1 = load_sim3(A.states + A.ev1[k]);
-    double e[7];
-    sim3::edge_error(C, S0, S1, A.opts, e);
-#pragma unroll
-    for (int r = 0; r < 7; ++r) out[(size_t)7 * k + r] = e[r];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// linearisation, numeric Jacobians (g2o default for EdgeSim3)
-//   half-wavefront (32 lanes) per edge, 8 edges per 256-thread workgroup:
-//     lanes 0-13 : e(exp(+-delta e_d) S0, S1), d = lane/2        -> columns of A
-//     lanes 14-27: e(S0, exp(+-delta e_d) S1)                     -> columns of B
-//     lane 28    : unperturbed e
-//   then the 14x14 Gram matrix J^T W J and -J^T W e are formed from LDS and written with plain
-//   stores: off-diagonal 7x7 blocks straight into the block-CSR values (this edge owns them),
-//   diagonal contributions into the per-incidence scratch reduced by k_diag_reduce.
-// ------------------------------------------------------------------------------------------
-struct LinArgs {
-  int32_t n_active;
-  const int32_t* active;
-  const int32_t* ev0;
-  const int32_t* ev1;
-  const Sim3* meas;
-  const double* info;
-  const double* kdelta;
-  const Sim3* states;
-  const int32_t* slot01;
-  const int32_t* slot10;
-  const int32_t* inc0;
-  const int32_t* inc1;
-  double* vals;
-  double* scratch;
-  double delta;
-  sim3::Opts opts;
-  int32_t dof_mask;  // cleared bit d: Jacobian column d of both endpoints is zero (frozen DoF)
-  DevScalars* sc;    // max |H_dd| starts from zero here (k_diag_reduce, the next launch, raises it)
-};
-
-struct GramTables {
-  unsigned char ga[119], gb[119];  // Gram tasks: (a, b) with a <= b < 14, or b == 14 for J^T W e
-  unsigned char tr[28], tc[28];    // upper triangle (r <= c) in column-major order
-};
-__constant__ GramTables c_tab;
-
-constexpr int EPB = 8;  // edges per workgroup
-
-template <bool HAS_INFO, bool HAS_KERNEL>
-__global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
-  __shared__ double s_in[EPB][24];
-  __shared__ double s_J[EPB][15][7];                    // 14 Jacobian columns, column 14 = e
-  __shared__ double s_O[HAS_INFO ? EPB : 1][15][7];     // Omega * (J | e)
-  __shared__ double s_G[EPB][14][15];                   // upper Gram + column 14 = -J^T W e
-  const int l = threadIdx.x & 31, es = threadIdx.x >> 5;
-  const int ai = blockIdx.x * EPB + es;
-  const bool valid = ai < A.n_active;
-  if (blockIdx.x == 0 && threadIdx.x == 0) A.sc->maxdiag_bits = 0ull;  // (instead of a memset: 18 us of host latency)
-  int edge = 0;
-  if (valid) {
-    edge = A.active[ai];
-    // coalesced 64-B reads: measurement and the two vertex states, staged in LDS
-    if (l < 8) s_in[es][l] = reinterpret_cast<const double*>(A.meas + edge)[l];
-    else if (l < 16) s_in[es][l] = reinterpret_cast<const double*>(A.states + A.ev0[edge])[l - 8];
-    else if (l < 24) s_in[es][l] = reinterpret_cast<const double*>(A.states + A.ev1[edge])[l - 16];
-  }
-  __syncthreads();
-  double e[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (valid && l < 29) {
-    Sim3 C, S0, S1;
-    const double* in = s_in[es];
-    C.q[0] = in[0]; C.q[1] = in[1]; C.q[2] = in[2]; C.q[3] = in[3];
-    C.t[0] = in[4]; C.t[1] = in[5]; C.t[2] = in[6]; C.s = in[7];
-    S0.q[0] = in[8]; S0.q[1] = in[9]; S0.q[2] = in[10]; S0.q[3] = in[11];
-    S0.t[0] = in[12]; S0.t[1] = in[13]; S0.t[2] = in[14]; S0.s = in[15];
-    S1.q[0] = in[16]; S1.q[1] = in[17]; S1.q[2] = in[18]; S1.q[3] = in[19];
-    S1.t[0] = in[20]; S1.t[1] = in[21]; S1.t[2] = in[22]; S1.s = in[23];
-    if (l < 28) {
-      const int d = (l % 14) >> 1;
-      const double step = (l & 1) ? -A.delta : A.delta;
-      double xi[7];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) xi[i] = (i == d) ? step : 0.0;
-      const Sim3 P = sim3::exp(xi, A.opts);
-      if (l < 14) S0 = sim3::mul(P, S0);
-      else S1 = sim3::mul(P, S1);
-    }
-    sim3::edge_error(C, S0, S1, A.opts, e);
-  }
-  const double scalar = 1.0 / (2.0 * A.delta);
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const double other = __shfl_down(e[r], 1);  // lane l+1 holds the -delta evaluation
-    if (valid && l < 28 && !(l & 1))
-      s_J[es][l >> 1][r] = ((A.dof_mask >> ((l % 14) >> 1)) & 1) ? scalar * (e[r] - other) : 0.0;
-    if (valid && l == 28) s_J[es][14][r] = e[r];
-  }
-  __syncthreads();
-  if (HAS_INFO) {
-    if (valid) {
-      const double* Om = A.info + (size_t)49 * edge;  // column-major
-      for (int t = l; t < 105; t += 32) {
-        const int a = t / 7, r = t % 7;
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += Om[7 * k + r] * s_J[es][a][k];
-        s_O[es][a][r] = acc;
-      }
-    }
-    __syncthreads();
-  }
-  double (*OJ)[7] = HAS_INFO ? s_O[es] : s_J[es];
-  double w = 1.0;
-  if (HAS_KERNEL) {
-    if (valid && A.kdelta[edge] > 0.0) {
-      double chi = 0.0, rho;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) chi += s_J[es][14][r] * OJ[14][r];
-      huber(chi, A.kdelta[edge], rho, w);
-    }
-  }
-  if (valid) {
-    for (int t = l; t < 119; t += 32) {
-      const int a = c_tab.ga[t], b = c_tab.gb[t];
-      double acc = 0.0;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) acc += s_J[es][a][r] * OJ[b][r];
-      s_G[es][a][b] = (b == 14 ? -w : w) * acc;
-    }
-  }
-  __syncthreads();
-  if (valid) {
-    const int s01 = A.slot01[edge], s10 = A.slot10[edge];
-    const int i0 = A.inc0[edge], i1 = A.inc1[edge];
-    double (*G)[15] = s_G[es];
-    for (int o = l; o < 168; o += 32) {
-      if (o < 49) {  // H01 = A^T W B, column-major
-        if (s01 >= 0) A.vals[(size_t)49 * s01 + o] = G[o % 7][7 + o / 7];
-      } else if (o < 98) {  // H10 = H01^T
-        const int p = o - 49;
-        if (s10 >= 0) A.vals[(size_t)49 * s10 + p] = G[p / 7][7 + p % 7];
-      } else if (o < 133) {  // endpoint 0: upper(A^T W A), -A^T W e
-        const int t = o - 98;
-        if (i0 >= 0)
-          A.scratch[(size_t)35 * i0 + t] = t < 28 ? G[c_tab.tr[t]][c_tab.tc[t]] : G[t - 28][14];
-      } else {  // endpoint 1
-        const int t = o - 133;
-        if (i1 >= 0)
-          A.scratch[(size_t)35 * i1 + t] =
-              t < 28 ? G[7 + c_tab.tr[t]][7 + c_tab.tc[t]] : G[7 + t - 28][14];
-      }
-    }
-  }
-}
-
-// One wavefront per block row: sums the per-incidence contributions in edge order, writes the
-// full symmetric diagonal block and b, tracks max |H_dd| (computeLambdaInit).
-__global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
-                                                    const int32_t* __restrict__ incptr,
-                                                    const int32_t* __restrict__ rowptr,
-                                                    const double* __restrict__ scratch,
-                                                    double* __restrict__ vals,
-                                                    double* __restrict__ b, DevScalars* sc,
-                                                    double* __restrict__ trace_partials) {
-  __shared__ double sh[4];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int r = lane % 7, c = lane / 7;
-  const int m = r < c ? r : c, M = r < c ? c : r;
-  const int tsrc = lane < 49 ? (M * (M + 1)) / 2 + m : 0;
-  const int bsrc = lane < 7 ? 28 + lane : 0;
-  double dmax = 0.0, tr = 0.0;
-  for (int row = r0 + blockIdx.x * 4 + wave; row < r1; row += gridDim.x * 4) {
-    const int k0 = incptr[row], k1 = incptr[row + 1];
-    double sum = 0.0;
-    if (lane < 35)
-      for (int k = k0; k < k1; ++k) sum += scratch[(size_t)35 * k + lane];
-    const double v = __shfl(sum, tsrc);
-    const double bv = __shfl(sum, bsrc);
-    if (lane < 49) {
-      vals[(size_t)49 * rowptr[row] + lane] = v;
-      if (r == c) {
-        dmax = fmax(dmax, fabs(v));
-        tr += v;
-      }
-    }
-    if (lane < 7) b[(size_t)7 * row + lane] = bv;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
-  if (lane == 0 && dmax > 0.0)
-    atomicMax(&sc->maxdiag_bits, (unsigned long long)__double_as_longlong(dmax));
-  const double ts = block_sum(tr, sh);  // fixed order: deterministic
-  if (threadIdx.x == 0) trace_partials[blockIdx.x] = ts;
-}
-
-// ------------------------------------------------------------------------------------------
-// block-Jacobi preconditioner / smoother: Minv = omega (D + lambda W)^-1, one lane per block row
-// (Gauss-Jordan without pivoting; positive pivots <=> SPD block).  Level 0 of the system:
-// D = the row's diagonal block, W = I.  Coarse multigrid levels (diagH, W given): D = the undamped
-// Galerkin diagonal block, W = P^T P; the damped block is also stored back into vals.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __restrict__ rowptr,
-                                               double* __restrict__ vals, double lambda,
-                                               double* __restrict__ Minv, DevScalars* sc,
-                                               double omega, const double* __restrict__ diagH,
-                                               const double* __restrict__ W,
-                                               float* __restrict__ vals32 = nullptr) {
-  const int row = r0 + blockIdx.x * WG + threadIdx.x;
-  if (row >= r1) return;
-  double a[7][7];
-  double* blk = vals + (size_t)49 * rowptr[row];
-  const int64_t kd = rowptr[row];  // the row's diagonal block
-  const double* src = diagH ? diagH + (size_t)49 * row : blk;
-#pragma unroll
-  for (int c = 0; c < 7; ++c)
-#pragma unroll
-    for (int r = 0; r < 7; ++r) a[r][c] = src[7 * c + r];
-  if (W) {
-    const double* w = W + (size_t)49 * row;
-#pragma unroll
-    for (int c = 0; c < 7; ++c)
-#pragma unroll
-      for (int r = 0; r < 7; ++r) {
-        a[r][c] += lambda * w[7 * c + r];
-        blk[7 * c + r] = a[r][c];
-        if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
-      }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) a[i][i] += lambda;
-  }
-  bool spd = true;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    if (!(a[k][k] > 0.0)) spd = false;
-    const double d = 1.0 / a[k][k];
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-      if (j != k) a[k][j] *= d;
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-      if (i != k) {
-        const double f = a[i][k];
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (j != k) a[i][j] -= f * a[k][j];
-        a[i][k] = -f * d;
-      }
-    a[k][k] = d;
-  }
-  if (!spd) sc->fail = 1;
-  double* dst = Minv + (size_t)49 * row;  // row-major
-#pragma unroll
-  for (int r = 0; r < 7; ++r)
-#pragma unroll
-    for (int c = 0; c < 7; ++c) dst[7 * r + c] = omega * a[r][c];
-}
-
-// FP32 copy of a block array (the multigrid's matrix passes read it)
-__global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restrict__ src,
-                                               float* __restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    dst[f32_pair_index((int64_t)(i / 49), (int)(i % 49))] = (float)src[i];
-}
-
+#include "lm_kernels.hpp"
 #include "amg_kernels.hpp"
 #include "direct_kernels.hpp"
 #include "symm_proto.hpp"
 
-// ------------------------------------------------------------------------------------------
-// PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
-// row's 7 entries sit in one wavefront (z = Minv r by shuffles) and addresses stay contiguous.
-// ------------------------------------------------------------------------------------------
-// q = (H + lambda I) p with the partial dot products p.q and (optionally) rvec.p per workgroup --
-// the block-CSR SpMV of the PCG (LinearSolverEigen's role, kitti_surf.cpp:553-554).
-// One wavefront owns a CONTIGUOUS span of block rows (host table `wrow`, balanced by block count);
-// lane = one of the 49 entries of the current 7x7 block, so its blocks and column indices are one
-// contiguous HBM stream, software-pipelined across row boundaries:
-//   * the loads of chunk k+1 (CH blocks of 392 B + ONE shared gather of p: lane 7u+c reads
-//     p[7 col_u + c]) are in flight while chunk k is consumed; the p entries reach the (r, c) lanes
-//     through the LDS crossbar (ds_bpermute), which is otherwise idle -- with one gather per block
-//     the address unit, not HBM, was the co-bottleneck (measured);
-//   * lanes 49..63 mirror lanes 0..14: every lane issues a valid coalesced load, no exec masking;
-//   * column indices / row ends: one coalesced vector load per 64, then v_readlane / ds_bpermute;
-//   * NT: the once-read block stream bypasses the cache policy so p stays in L2 / Infinity Cache;
-//   * a row ends with a wave-uniform branch (reduce 7 columns, add lambda p, store q, dots).
-// MODE 0: q = A p (+ the dot partials; the PCG's SpMV).  The multigrid preconditioner reuses the
-// same stream for its two matrix passes per level: MODE 1: q = rvec - A p (residual),
-// MODE 2: q = p + Minv (rvec - A p) (one damped block-Jacobi step; Minv = omega D^-1, row-major).
-// MODE 3 (coarse multigrid levels): MODE 2 applied to p + xc[agg] -- the piecewise-constant
-// prolongation of the coarser level's correction is added while the input vector is gathered
-// (xc through `partials_r`, which the non-PCG modes do not use).
-// VT = float: the multigrid preconditioner's matrix passes stream an FP32 copy of the blocks (half
-// the bytes; vectors, accumulation and the smoother inverses stay FP64) -- the PCG's own SpMV
-// (MODE 0) always reads the FP64 blocks.
-template <int CH, bool NT, int MODE, typename VT = double>
-__global__ __launch_bounds__(WG)
-// (the FP32 smoothing pass also carries the r.z partial now: keep it at 6 wavefronts per SIMD, 80 VGPRs)
-__attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
-                                                  const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ colidx,
-                                                  const VT* __restrict__ vals,
-                                                  const double* __restrict__ p,
-                                                  double* __restrict__ q, double lambda,
-                                                  double* __restrict__ partials,
-                                                  const double* __restrict__ rvec,
-                                                  double* __restrict__ partials_r,
-                                                  DevScalars* __restrict__ sc,
-                                                  const double* __restrict__ Minv, int lam_sc,
-                                                  const int32_t* __restrict__ agg,
-                                                  double xc_scale) {
-  __shared__ double sh[4];
-  __shared__ double sh2[4];
-  __shared__ int sh_cnt;
-  if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
-    if (threadIdx.x == 0) sh_cnt = 0;
-    __syncthreads();
-  }
-  if (sc) {
-    if (sc->done) return;
-    if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
-    // the previous update was the last allowed one: later launches become no-ops
-    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-      if (sc->stop) sc->done = 1;
-      sc->n_spmv_work += 1;  // (launches are stream-ordered: one writer at a time)
-    }
-  }
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  const int r = lane % 7;
-  const int l49 = lane < 49 ? lane : lane - 49;
-  const int c49 = l49 / 7;
-  const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
-  const int rA = wrow[w], rB = wrow[w + 1];
-  double pq = 0.0, pr = 0.0;
-  // per-row operands are requested when the row starts and consumed when it ends
-  double pi_n = 0.0, rv_n = 0.0, mv = 0.0;
-  // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
-  // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
-  // instruction per row; the kernel is bound by the number of those, not by their bytes)
-  auto row_begin = [&](int row, int u, double xg) {
-    pi_n = __shfl(xg, 7 * u + r);
-    if (rvec) rv_n = rvec[(size_t)7 * row + r];
-    if (MODE >= 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
-  };
-  // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
-  // (row sums are valid in lanes 0..6)
-  auto row_end = [&](int row, double acc) {
-    double y = acc;
-#pragma unroll
-    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-    const double pi = pi_n;
-    y += lambda * pi;
-    if (MODE == 0) {
-      if (lane < 7) {
-        q[(size_t)7 * row + lane] = y;
-        pq += pi * y;
-        if (rvec) pr += rv_n * pi;
-      }
-    } else {
-      const double d = rv_n - y;
-      if (MODE == 1) {
-        if (lane < 7) q[(size_t)7 * row + lane] = d;
-      } else {
-        const double pr_ = mv * __shfl(d, c49);  // Minv(r, c) d_c
-        double o = pr_;
-#pragma unroll
-        for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
-        if (lane < 7) {
-          const double zo = pi + o;
-          q[(size_t)7 * row + lane] = zo;
-          // the PCG's r.z where z is born (level 0's last pass writes z = M^-1 r and holds r): the
-          // SpMV that follows then needs no load of r -- 11 us of its 166 (measured)
-          if (MODE == 2 && partials) pr += rv_n * zo;
-        }
-      }
-    }
-  };
-  if (rA < rB) {
-    const int kbeg = rowptr[rA], kend = rowptr[rB];
-    // row ends of this span, 64 at a time, one per lane
-    int rbase = rA;
-    int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
-    int row = rA;
-    int k1 = __builtin_amdgcn_readlane(rpv, 0);
-    // FP32 blocks come in interleaved pairs (f32_pair_index): chunks start at an even block index,
-    // a leading block of the previous span is loaded and skipped
-    constexpr bool PAIR = sizeof(VT) == 4;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int k0 = PAIR ? (kbeg & ~1) : kbeg;
-    const int pmax = (kend - 1) >> 1;
-    auto load_chunk = [&](int ks, VT* dst) {
-      if (PAIR) {
-#pragma unroll
-        for (int u = 0; u < CH; u += 2) {
-          const int pp = (ks + u) >> 1;
-          const f32x2* vp = reinterpret_cast<const f32x2*>(vals) + (size_t)49 * (pp < pmax ? pp : pmax) + l49;
-          const f32x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
-          dst[u] = (VT)t.x;
-          dst[u + 1] = (VT)t.y;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int kk = ks + u < kend ? ks + u : kend - 1;
-          const VT* vp = vals + (size_t)49 * kk + l49;
-          dst[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
-        }
-      }
-    };
-    // column indices, 64 blocks at a time, one per lane; window w covers [k0 + 64 w, +64)
-    int cbase = k0;
-    int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
-    int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
-    double acc = 0.0;
-    VT vc[CH], vn[CH];
-    double xgc, xgn = 0.0;
-    // prologue: chunk at k0
-    {
-      load_chunk(k0, vc);
-      const int kk = k0 + gu < kend ? k0 + gu : kend - 1;
-      const int colu = __shfl(cv, kk - cbase);
-      xgc = p[(size_t)7 * colu + gc];
-      if (MODE == 3) xgc += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
-    }
-    row_begin(row, kbeg - k0, xgc);
-    for (int k = k0; k < kend; k += CH) {
-      const int kn = k + CH;
-      if (kn < kend) {  // issue the next chunk before consuming this one
-        if (kn - cbase >= 64) {  // next chunk starts a new 64-block window (CH divides 64)
-          cbase += 64;
-          cv = cvn;
-          cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
-        }
-        load_chunk(kn, vn);
-        const int kk = kn + gu < kend ? kn + gu : kend - 1;
-        const int colu = __shfl(cv, kk - cbase);
-        xgn = p[(size_t)7 * colu + gc];
-        if (MODE == 3) xgn += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
-      }
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int kk = k + u;
-        if (kk >= kbeg && kk < kend) {
-          if (kk == k1) {  // row `row` is complete
-            row_end(row, acc);
-            acc = 0.0;
-            ++row;
-            row_begin(row, u, xgc);
-            if (row - rbase >= 64) {
-              rbase += 64;
-              rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
-            }
-            k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
-          }
-          acc += (double)vc[u] * __shfl(xgc, 7 * u + c49);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < CH; ++u) vc[u] = vn[u];
-      xgc = xgn;
-    }
-    row_end(row, acc);  // last row of the span
-  }
-  if (MODE == 2 && partials) {
-    // no barrier at the end of a streaming kernel: every wavefront leaves its sum in LDS and goes;
-    // the one that arrives last adds the four in index order (deterministic) and writes the partial
-    const double t = wave_sum(pr);
-    if (lane == 0) {
-      sh[threadIdx.x >> 6] = t;
-      __threadfence_block();
-      if (atomicAdd(&sh_cnt, 1) == 3) {
-        __threadfence_block();
-        partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-      }
-    }
-    return;
-  }
-  if (MODE != 0) return;
-  {  // the same barrier-free partial sums (w.z, and r.z when this pass reads r)
-    const double s = wave_sum(pq);
-    const double t = rvec ? wave_sum(pr) : 0.0;
-    if (lane == 0) {
-      sh[threadIdx.x >> 6] = s;
-      sh2[threadIdx.x >> 6] = t;
-      __threadfence_block();
-      if (atomicAdd(&sh_cnt, 1) == 3) {
-        __threadfence_block();
-        if (partials) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        if (rvec) partials_r[blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
-      }
-    }
-  }
-}
-
-// x = 0, r = b, z = Minv b (block-Jacobi; the chain preconditioner runs separately), p = s = 0
-__global__ __launch_bounds__(WG) void k_pcg_init(int r0, int r1, const double* __restrict__ b,
-                                                 const double* __restrict__ Minv,
-                                                 double* __restrict__ x, double* __restrict__ r,
-                                                 double* __restrict__ z, double* __restrict__ p,
-                                                 double* __restrict__ sv) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
-    const int row = row0 + sub;
-    const bool act = lane < 63 && row < r1;
-    const size_t j = (size_t)7 * row + rr;
-    const double rv = act ? b[j] : 0.0;
-    if (act) {
-      x[j] = 0.0;
-      r[j] = rv;
-      p[j] = 0.0;
-      sv[j] = 0.0;
-    }
-    if (Minv) {
-      double zv = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 7; ++cc) {
-        const double rc = __shfl(rv, base + cc);
-        if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
-      }
-      if (act) z[j] = zv;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Chain-segment preconditioner (option `preconditioner`): M = the block-tridiagonal part of
-// H + lambda I inside segments of `seg` consecutive block rows (diagonal blocks plus the blocks
-// between rows i and i-1, i.e. the odometry chain of kitti_surf.cpp:649-670), factored exactly:
-//   S_i = D_i + lambda I - G_i L_i^T,  G_i = L_i S_{i-1}^-1,  L_i = H(i, i-1)   (block LDL^T)
-// For chain-like graphs (KITTI-00: 770 rows, 1..118 loops) the preconditioned operator is the
-// identity plus a low-rank term (14 per loop or cut link), so PCG needs tens of iterations where
-// block-Jacobi needs 1e4.  It does not help loop-dominated graphs (measured).
-// ------------------------------------------------------------------------------------------
-// factorisation: one lane per segment (once per LM trial; sequential by nature)
-__global__ __launch_bounds__(64) void k_chain_factor(int r0, int r1, int seg,
-                                                     const int32_t* __restrict__ rowptr,
-                                                     const double* __restrict__ vals,
-                                                     const int32_t* __restrict__ sub_first,
-                                                     const int32_t* __restrict__ sub_cnt,
-                                                     double lambda, double* __restrict__ Sinv,
-                                                     double* __restrict__ Gm, DevScalars* sc) {
-  const int sidx = blockIdx.x * 64 + threadIdx.x;
-  const long long start = (long long)r0 + (long long)sidx * seg;
-  if (start >= r1) return;
-  const int row_end = (int)(start + seg < r1 ? start + seg : r1);
-  double P[7][7];  // S_{i-1}^-1
-  bool spd = true;
-  for (int i = (int)start; i < row_end; ++i) {
-    double a[7][7], G[7][7];
-    const double* d = vals + (size_t)49 * rowptr[i];
-    for (int c = 0; c < 7; ++c)
-      for (int r = 0; r < 7; ++r) a[r][c] = d[7 * c + r];
-    for (int k = 0; k < 7; ++k) a[k][k] += lambda;
-    const int nsub = i > start ? sub_cnt[i] : 0;
-    if (nsub > 0) {
-      double Lm[7][7];
-      for (int r = 0; r < 7; ++r)
-        for (int c = 0; c < 7; ++c) Lm[r][c] = 0.0;
-      for (int t = 0; t < nsub; ++t) {  // parallel edges between i and i-1 keep separate blocks
-        const double* l = vals + (size_t)49 * (sub_first[i] + t);
-        for (int c = 0; c < 7; ++c)
-          for (int r = 0; r < 7; ++r) Lm[r][c] += l[7 * c + r];
-      }
-      for (int r = 0; r < 7; ++r)
-        for (int c = 0; c < 7; ++c) {
-          double acc = 0.0;
-          for (int k = 0; k < 7; ++k) acc += Lm[r][k] * P[k][c];
-          G[r][c] = acc;
-        }
-      for (int r = 0; r < 7; ++r)
-        for (int c = 0; c < 7; ++c) {
-          double acc = 0.0;
-          for (int k = 0; k < 7; ++k) acc += G[r][k] * Lm[c][k];
-          a[r][c] -= acc;
-        }
-    } else {
-      for (int r = 0; r < 7; ++r)
-        for (int c = 0; c < 7; ++c) G[r][c] = 0.0;
-    }
-    for (int k = 0; k < 7; ++k) {  // Gauss-Jordan, positive pivots <=> SPD
-      if (!(a[k][k] > 0.0)) spd = false;
-      const double dd = 1.0 / a[k][k];
-      for (int j = 0; j < 7; ++j)
-        if (j != k) a[k][j] *= dd;
-      for (int r = 0; r < 7; ++r)
-        if (r != k) {
-          const double f = a[r][k];
-          for (int j = 0; j < 7; ++j)
-            if (j != k) a[r][j] -= f * a[k][j];
-          a[r][k] = -f * dd;
-        }
-      a[k][k] = dd;
-    }
-    double* so = Sinv + (size_t)49 * i;
-    double* go = Gm + (size_t)49 * i;
-    for (int r = 0; r < 7; ++r)
-      for (int c = 0; c < 7; ++c) {
-        so[7 * r + c] = a[r][c];
-        go[7 * r + c] = G[r][c];
-        P[r][c] = a[r][c];
-      }
-  }
-  if (!spd) sc->fail = 1;
-}
-
-// application z = M^-1 r and partial r.z: one wavefront per segment, lane = (row rr, column cc)
-// of the 7x7 factor blocks; forward pass y_i = r_i - G_i y_{i-1} (kept in LDS), backward pass
-// z_i = S_i^-1 y_i - G_{i+1}^T z_{i+1}.  Two dependent shuffles per row and direction.
-constexpr int CHAIN_SEG_MAX = 256;
-__global__ __launch_bounds__(WG) void k_chain_apply(int r0, int r1, int seg,
-                                                    const double* __restrict__ Sinv,
-                                                    const double* __restrict__ Gm,
-                                                    const double* __restrict__ r,
-                                                    double* __restrict__ z,
-                                                    const DevScalars* __restrict__ sc) {
-  __shared__ double ybuf[4][CHAIN_SEG_MAX * 7];
-  if (sc && sc->done) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int l49 = lane < 49 ? lane : lane - 49;
-  const int rr = l49 / 7, cc = l49 % 7;
-  const int nseg = (r1 - r0 + seg - 1) / seg;
-  for (int sidx = blockIdx.x * 4 + wave; sidx < nseg; sidx += gridDim.x * 4) {
-    const int start = r0 + sidx * seg;
-    const int end = start + seg < r1 ? start + seg : r1;
-    double* yb = ybuf[wave];
-    // forward
-    double yprev_cc = 0.0;
-    double g_nx = Gm[(size_t)49 * start + 7 * rr + cc], r_nx = r[(size_t)7 * start + rr];
-    for (int i = start; i < end; ++i) {
-      const double g = g_nx, ri = r_nx;
-      if (i + 1 < end) {  // the next row's factor block and rhs are in flight during this row's shuffles
-        g_nx = Gm[(size_t)49 * (i + 1) + 7 * rr + cc];
-        r_nx = r[(size_t)7 * (i + 1) + rr];
-      }
-      const double prod = g * yprev_cc;
-      double sum = 0.0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) sum += __shfl(prod, 7 * rr + k);
-      const double yi = ri - sum;  // y_i[rr], identical on the 7 lanes of row rr
-      yprev_cc = __shfl(yi, 7 * cc);                   // y_i[cc] for the next row
-      if (cc == 0 && lane < 49) yb[7 * (i - start) + rr] = yi;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // backward
-    double znext_cc = 0.0;
-    double s_nx = Sinv[(size_t)49 * (end - 1) + 7 * rr + cc], gt_nx = 0.0;
-    for (int i = end - 1; i >= start; --i) {
-      const double yc = yb[7 * (i - start) + cc];
-      const double sv = s_nx, gt = gt_nx;  // S_i^-1 and G_{i+1}^T entries, prefetched
-      if (i > start) {
-        s_nx = Sinv[(size_t)49 * (i - 1) + 7 * rr + cc];
-        gt_nx = Gm[(size_t)49 * i + 7 * cc + rr];
-      }
-      double prod = sv * yc;
-      if (i + 1 < end) prod -= gt * znext_cc;  // G_{i+1}^T
-      double zi = 0.0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) zi += __shfl(prod, 7 * rr + k);
-      znext_cc = __shfl(zi, 7 * cc);
-      if (cc == 0 && lane < 49) z[(size_t)7 * i + rr] = zi;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// One PCG iteration in the single-reduction form (Chronopoulos & Gear): the SpMV launch before
-// this one produced w = (H + lambda I) z and the partials of delta = w.z and gamma = r.z, so the
-// iteration has ONE reduction point (one 2-double all-reduce on multi-GPU) and two launches:
-//   beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)
-//   p = z + beta p,  s = w + beta s (= A p),  x += alpha p,  r -= alpha s,  z = Minv r
-// Workgroup 0 commits gamma / alpha for the next launch (ping-pong by parity, so no workgroup
-// reads what another one writes in the same launch) and the stopping decision.
-__global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it,
-                                                 const double* __restrict__ scal,
-                                                 const double* __restrict__ part_d,
-                                                 const double* __restrict__ part_g, int npart,
-                                                 const double* __restrict__ Minv,
-                                                 const double* zin, double* zout,
-                                                 const double* __restrict__ w,
-                                                 double* __restrict__ p, double* __restrict__ sv,
-                                                 double* __restrict__ x, double* __restrict__ r,
-                                                 DevScalars* sc) {
-  __shared__ double sh[4];
-  if (sc->done) return;
-  const double delta = scal ? scal[0] : sum_partials(part_d, npart, sh);
-  const double gamma = scal ? scal[1] : sum_partials(part_g, npart, sh);
-  const bool first = it == 0;  // it < 0: a captured (replayed) launch, never the first iteration
-  const double gamma0 = first ? gamma : sc->rz0;
-  const bool commit = blockIdx.x == 0 && threadIdx.x == 0;
-  if (!(gamma == gamma) || gamma < 0.0 || gamma <= sc->tol2 * gamma0 || (first && gamma == 0.0)) {
-    if (commit) {  // converged (x is final) or broken down; every workgroup sees the same gamma
-      if (!(gamma == gamma) || gamma < 0.0) sc->fail = 1;
-      if (first) sc->rz0 = gamma;
-      sc->rz[par ^ 1] = gamma;
-      sc->gam_last = gamma;
-      sc->done = 1;
-    }
-    return;
-  }
-  const double beta = first ? 0.0 : gamma / sc->rz[par];
-  const double denom = first ? delta : delta - beta * gamma / sc->alpha[par];
-  if (!(denom > 0.0) || !(denom < DBL_MAX)) {  // not positive definite (g2o: Cholesky fails)
-    if (commit) {
-      sc->fail = 1;
-      sc->done = 1;
-    }
-    return;
-  }
-  const double alpha = gamma / denom;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  for (int row0 = r0 + (blockIdx.x * 4 + wave) * 9; row0 < r1; row0 += gridDim.x * 36) {
-    const int row = row0 + sub;
-    const bool act = lane < 63 && row < r1;
-    const size_t j = (size_t)7 * row + rr;
-    double rv = 0.0;
-    if (act) {
-      const double pn = zin[j] + beta * p[j];
-      const double sn = w[j] + beta * sv[j];
-      p[j] = pn;
-      sv[j] = sn;
-      x[j] += alpha * pn;
-      rv = r[j] - alpha * sn;
-      r[j] = rv;
-    }
-    if (Minv) {
-      double zv = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 7; ++cc) {
-        const double rc = __shfl(rv, base + cc);
-        if (act) zv += Minv[(size_t)49 * row + 7 * rr + cc] * rc;
-      }
-      if (act) zout[j] = zv;
-    }
-  }
-  if (commit) {
-    if (first) sc->rz0 = gamma;
-    sc->rz[par ^ 1] = gamma;
-    sc->gam_last = gamma;
-    sc->alpha[par ^ 1] = alpha;
-    const int itn = (it < 0 ? sc->iter : it) + 1;  // only this thread ever writes sc->iter
-    sc->iter = itn;
-    if (itn >= sc->max_iter) sc->stop = 1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// update and scale
-// ------------------------------------------------------------------------------------------
-// VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
-// (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
-// fact; the step is then garbage and must not be applied -- the host rejects the trial)
-// `backup` (may be null) receives the estimates as they were: g2o's push() without a copy of its own.
-__global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
-                                              const double* __restrict__ x, Sim3* states,
-                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup) {
-  const int v = blockIdx.x * WG + threadIdx.x;
-  if (v >= nv) return;
-  if (backup) {
-    const double* s8 = reinterpret_cast<const double*>(states + v);
-    double* b8 = reinterpret_cast<double*>(backup + v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b8[i] = s8[i];
-  }
-  if (sc && sc->fail) return;
-  const int h = hidx[v];
-  if (h < 0) return;
-  double xi[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) xi[i] = x[(size_t)7 * h + i];
-  const Sim3 P = sim3::exp(xi, opts);
-  const Sim3 S = sim3::mul(P, load_sim3(states + v));
-  double* d = reinterpret_cast<double*>(states + v);
-  d[0] = S.q[0]; d[1] = S.q[1]; d[2] = S.q[2]; d[3] = S.q[3];
-  d[4] = S.t[0]; d[5] = S.t[1]; d[6] = S.t[2]; d[7] = S.s;
-}
-
-// pop(): the estimates of a rejected trial go back (a kernel: hipMemcpyAsync costs the host 6-18 us)
-__global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restrict__ src, Sim3* __restrict__ dst) {
-  const int i = blockIdx.x * WG + threadIdx.x;
-  if (i < 8 * nv) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
-}
-
-__global__ void k_reset_fail(DevScalars* sc) { sc->fail = 0; }
-
-// Halo exchange of the row-partitioned PCG (round 3): the boundary rows of a vector (rows with a
-// neighbour on another rank, host list `brow`, grouped by owner) are packed into one buffer, that
-// buffer is all-gathered (each rank contributes its own segment), and every foreign boundary row is
-// written back into the full-length vector -- instead of all-gathering the whole vector.
-__global__ __launch_bounds__(WG) void k_halo_pack(int k0, int k1, const int32_t* __restrict__ brow,
-                                                  const double* __restrict__ vec, double* __restrict__ buf) {
-  const int t = blockIdx.x * WG + threadIdx.x;
-  const int k = k0 + t / 7, c = t % 7;
-  if (k < k1 && brow[k] >= 0) buf[(size_t)7 * k + c] = vec[(size_t)7 * brow[k] + c];
-}
-__global__ __launch_bounds__(WG) void k_halo_unpack(int n, int own0, int own1, const int32_t* __restrict__ brow,
-                                                    const double* __restrict__ buf, double* __restrict__ vec) {
-  const int t = blockIdx.x * WG + threadIdx.x;
-  const int k = t / 7, c = t % 7;
-  if (k < n && (k < own0 || k >= own1) && brow[k] >= 0) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
-}
-
-// computeScale: sum_j x_j (lambda x_j + b_j)
-__global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
-                                              const double* __restrict__ b, double lambda,
-                                              double* __restrict__ partials) {
-  __shared__ double sh[4];
-  double acc = 0.0;
-  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
-    acc += x[j] * (lambda * x[j] + b[j]);
-  const double s = block_sum(acc, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
-// ||r||^2 and ||b||^2 over a row range (the multigrid path verifies what its stopping test claims)
-__global__ __launch_bounds__(WG) void k_norms2(int j0, int j1, const double* __restrict__ r,
-                                               const double* __restrict__ b,
-                                               double* __restrict__ pa, double* __restrict__ pb) {
-  __shared__ double sh[4];
-  double a = 0.0, c = 0.0;
-  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG) {
-    a += r[j] * r[j];
-    c += b[j] * b[j];
-  }
-  const double sa = block_sum(a, sh);
-  const double sb = block_sum(c, sh);
-  if (threadIdx.x == 0) {
-    pa[blockIdx.x] = sa;
-    pb[blockIdx.x] = sb;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// HBM read calibration (bench only): streams the block-CSR value array with different access
-// shapes so the SpMV's achieved rate can be read against what this access shape can reach.
-//   mode 0: 16 B per lane, all 64 lanes, contiguous          (the copy-kernel shape)
-//   mode 1:  8 B per lane, all 64 lanes, contiguous
-//   mode 2:  8 B per lane, 49 of 64 lanes, one 392-B block per wave-instruction (SpMV shape)
-// ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(WG) void k_stream_read(const double* __restrict__ src, size_t n,
-                                                    double* __restrict__ sink) {
-  double acc = 0.0;
-  const size_t tid = (size_t)blockIdx.x * WG + threadIdx.x, nth = (size_t)gridDim.x * WG;
-  if (MODE == 0) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2* s2 = reinterpret_cast<const d2*>(src);
-    const size_t n2 = n / 2;
-    for (size_t i = tid; i + 3 * nth < n2; i += 4 * nth) {
-      const d2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + nth);
-      const d2 c = __builtin_nontemporal_load(s2 + i + 2 * nth), d = __builtin_nontemporal_load(s2 + i + 3 * nth);
-      acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
-    }
-  } else if (MODE == 1) {
-    for (size_t i = tid; i + 7 * nth < n; i += 8 * nth) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += __builtin_nontemporal_load(src + i + u * nth);
-    }
-  } else {
-    const int lane = threadIdx.x & 63;
-    const int l49 = lane < 49 ? lane : lane - 49;
-    const size_t wid = tid >> 6, nw = nth >> 6, nblk = n / 49;
-    for (size_t k = wid * 8; k + 8 <= nblk; k += nw * 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += __builtin_nontemporal_load(src + 49 * (k + u) + l49);
-    }
-  }
-  if (acc == 123.456) sink[0] = acc;  // keep the loads alive
-}
+#include "pcg_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Engine
@@ -2185,8 +1175,10 @@ class Engine {
     const double* scal = pre_sum ? &d_sc->tmp_pq : nullptr;
     // automatic cap: small systems may need ~n iterations for an (almost) exact step like the
     // reference's Cholesky (chains are ill-conditioned); large ones get a truncated-Newton budget
+    // (with the hierarchy an iteration buys a fixed reduction: a cap of 1000 would truncate only the
+    // pathological systems of the as-written arithmetic, cond ~1e12 -- let those converge too)
     int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters
-                                       : (n <= 50000 ? std::max(100, 2 * n) : 1000);
+                                       : (n <= 50000 ? std::max(100, 2 * n) : (use_mg ? 4000 : 1000));
     if (probe) max_it = std::min(max_it, probe_budget);
     const int nseg = (nloc + chain_seg - 1) / chain_seg;
     const int gc = grid_for(nseg, 4);  // chain apply: one wavefront per segment
