@@ -59,8 +59,7 @@ typedef struct sim3opt_options {
   int32_t dof_mask;         /* 127   bit d set = tangent component d ([w0 w1 w2 u0 u1 u2 s]) is
                                         optimised; cleared bits freeze it (0x78 = rotations frozen:
                                         the scale+translation stage, kitti_surf.cpp:1020-1024)    */
-  int32_t pcg_max_iters;    /* 0 = automatic: 2n for n = 7*free vertices <= 50000, else 1000
-                               (4000 with the multigrid preconditioner)                    */
+  int32_t pcg_max_iters;    /* 0 = automatic: 2n for n = 7*free vertices <= 50000, else 1000 */
   double pcg_rel_tol;       /* 1e-10 stop when ||r||_Minv <= tol * ||b||_Minv            */
   int32_t pcg_check_every;  /* 16    PCG iterations between host convergence polls (at most 4 with the
                                         multigrid preconditioner: its iterations are ~1 ms each)  */
