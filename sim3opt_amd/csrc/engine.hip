@@ -52,6 +52,9 @@ using sim3::Sim3;
     }                                                                       \
   } while (0)
 
+#ifndef SIM3OPT_F32_CH
+#define SIM3OPT_F32_CH 8        // blocks per pipeline step of the level-0 FP32 passes (tuning: 16)
+#endif
 constexpr int WG = 256;         // 4 wavefronts of 64
 constexpr int PCG_GRAPH_ITERS = 16;  // PCG iterations per captured hipGraph (even: parity returns)
 constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
@@ -738,7 +741,7 @@ class Engine {
                      const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
                      (const int32_t*)L.agg, amg_over)
 #define AMG_SPMV32(NTV, MODEV)                                                                    \
-  hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
+  hipLaunchKernelGGL((k_spmv_span<(NTV) ? SIM3OPT_F32_CH : 8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
                      L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0,         \
                      rz_part, rvec, const_cast<double*>(xc),                                        \
                      level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over)

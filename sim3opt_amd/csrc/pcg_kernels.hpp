@@ -31,10 +31,14 @@
 // VT = float: the multigrid preconditioner's matrix passes stream an FP32 copy of the blocks (half
 // the bytes; vectors, accumulation and the smoother inverses stay FP64) -- the PCG's own SpMV
 // (MODE 0) always reads the FP64 blocks.
+#ifndef SIM3OPT_SPMV_FASTPATH
+#define SIM3OPT_SPMV_FASTPATH 1
+#endif
+constexpr bool FASTPATH = SIM3OPT_SPMV_FASTPATH != 0;
 template <int CH, bool NT, int MODE, typename VT = double>
 __global__ __launch_bounds__(WG)
 // (the FP32 smoothing pass also carries the r.z partial now: keep it at 6 wavefronts per SIMD, 80 VGPRs)
-__attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
+__attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 && CH == 8 ? 6 : 1))) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
                                                   const VT* __restrict__ vals,
@@ -68,7 +72,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
   const int r = lane % 7;
   const int l49 = lane < 49 ? lane : lane - 49;
   const int c49 = l49 / 7;
-  const int gu = lane / 7 < CH ? lane / 7 : CH - 1, gc = lane % 7;
+  constexpr int NG = (CH + 7) / 8;  // shared gathers of p per chunk: eight blocks each
+  const int gu = lane / 7 < 8 ? lane / 7 : 7, gc = lane % 7;
   const int rA = wrow[w], rB = wrow[w + 1];
   double pq = 0.0, pr = 0.0;
   // per-row operands are requested when the row starts and consumed when it ends
@@ -76,8 +81,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
   // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
   // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
   // instruction per row; the kernel is bound by the number of those, not by their bytes)
-  auto row_begin = [&](int row, int u, double xg) {
-    pi_n = __shfl(xg, 7 * u + r);
+  auto row_begin = [&](int row, int u, const double* xg) {
+    pi_n = __shfl(xg[u / 8], 7 * (u % 8) + r);
     if (rvec) rv_n = rvec[(size_t)7 * row + r];
     if (MODE >= 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
   };
@@ -152,15 +157,21 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
     int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
     double acc = 0.0;
     VT vc[CH], vn[CH];
-    double xgc, xgn = 0.0;
+    double xgc[NG], xgn[NG];
+    auto gather = [&](int ks, double* xg) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int kk = ks + 8 * g + gu < kend ? ks + 8 * g + gu : kend - 1;
+        const int colu = __shfl(cv, kk - cbase);
+        xg[g] = p[(size_t)7 * colu + gc];
+        if (MODE == 3) xg[g] += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < NG; ++g) xgn[g] = 0.0;
     // prologue: chunk at k0
-    {
-      load_chunk(k0, vc);
-      const int kk = k0 + gu < kend ? k0 + gu : kend - 1;
-      const int colu = __shfl(cv, kk - cbase);
-      xgc = p[(size_t)7 * colu + gc];
-      if (MODE == 3) xgc += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
-    }
+    load_chunk(k0, vc);
+    gather(k0, xgc);
     row_begin(row, kbeg - k0, xgc);
     for (int k = k0; k < kend; k += CH) {
       const int kn = k + CH;
@@ -171,32 +182,49 @@ __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 ? 6 : 1))) void 
           cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
         }
         load_chunk(kn, vn);
-        const int kk = kn + gu < kend ? kn + gu : kend - 1;
-        const int colu = __shfl(cv, kk - cbase);
-        xgn = p[(size_t)7 * colu + gc];
-        if (MODE == 3) xgn += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
+        gather(kn, xgn);
       }
+      // a chunk that lies inside the span and inside the current row (two in three on config 3) needs no
+      // per-block tests, and its shuffles are in flight together -- the same products in the same order
+      // (bit-identical; round 3, A/B on one box: -6.5 % on the FP64 pass, -13...16 % on the coarse levels'
+      // passes, the level-0 FP32 passes unchanged).  A third path for interior chunks WITH a row boundary
+      // (no validity tests) raised the register count and lost more than it won
+      // (profiles/r3_negative_results.log)
+      const bool interior = FASTPATH && k >= kbeg && k + CH <= kend;
+      auto next_row = [&](int u) {  // row `row` is complete; block u of this chunk starts the next one
+        row_end(row, acc);
+        acc = 0.0;
+        ++row;
+        row_begin(row, u, xgc);
+        if (row - rbase >= 64) {
+          rbase += 64;
+          rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
+        }
+        k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
+      };
+      if (interior && k1 >= k + CH) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int kk = k + u;
-        if (kk >= kbeg && kk < kend) {
-          if (kk == k1) {  // row `row` is complete
-            row_end(row, acc);
-            acc = 0.0;
-            ++row;
-            row_begin(row, u, xgc);
-            if (row - rbase >= 64) {
-              rbase += 64;
-              rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
-            }
-            k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
+        for (int h = 0; h < CH; h += 4) {  // (four at a time: eight live values cost the FP32 smoothing pass its occupancy)
+          double xs[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xs[u] = __shfl(xgc[(h + u) / 8], 7 * ((h + u) % 8) + c49);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += (double)vc[h + u] * xs[u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int kk = k + u;
+          if (kk >= kbeg && kk < kend) {
+            if (kk == k1) next_row(u);
+            acc += (double)vc[u] * __shfl(xgc[u / 8], 7 * (u % 8) + c49);
           }
-          acc += (double)vc[u] * __shfl(xgc, 7 * u + c49);
         }
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) vc[u] = vn[u];
-      xgc = xgn;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) xgc[g] = xgn[g];
     }
     row_end(row, acc);  // last row of the span
   }

@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsim3opt.so")
+# (tuning scripts A/B two builds of the library in one gpurun call: SIM3OPT_LIBRARY=<other .so>)
+LIB_PATH = os.environ.get("SIM3OPT_LIBRARY", LIB_PATH)
 
 OK, ERR_ARG, ERR_STATE, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_NONE, KERNEL_HUBER = 0, 1
