@@ -315,83 +315,207 @@ __global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __
 // whatever its work, so half the launches is half the time), out of place (B = step(A), buffers
 // ping-pong) so that no workgroup reads what another one overwrites:
 //   P = A_kk^-1;  B_kk = P;  B_kj = P A_kj;  B_ik = -A_ik P;  B_ij = A_ij - A_ik (P A_kj)
-// A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS; its first
-// wavefront inverts the pivot block with one row per lane (shuffles, no barrier).
+// A workgroup owns a 64 x 64 tile and keeps its slices of P A_k. and A_.k in LDS.  The inverse of the
+// pivot block is not on the step's critical path (round 3; it was 8 of a step's 23 us): P arrives
+// from the previous launch, and one extra workgroup (blockIdx.y == 0, dispatched first) looks ahead --
+// it updates the NEXT pivot block exactly as its tile would, inverts it in its first wavefront with
+// one row per lane (shuffles, no barrier) and leaves it for the next launch.
+
+// in-place Gauss-Jordan inverse of an NP x NP block, row `lane` in lane < NP of one wavefront
+template <int NP>
+__device__ inline bool gj_invert_rows(double (&prow)[NP], int lane) {
+  bool spd = true;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    double pk[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) pk[c] = __shfl(prow[c], k);
+    if (!(pk[k] > 0.0)) spd = false;
+    const double d = 1.0 / pk[k];
+    const double f = prow[k];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const double rk = pk[j] * d;  // scaled pivot row
+      if (lane == k) prow[j] = j == k ? d : rk;
+      else prow[j] = j == k ? -f * d : prow[j] - f * rk;
+    }
+  }
+  return spd;
+}
+
+// the same elimination with a row spread over two lanes: lane (r = lane & 31, h = lane >> 5) holds columns
+// [h NP/2, (h+1) NP/2) of row r -- half the multiply-adds, selects and cross-lane reads per lane (a 28 x 28
+// block: 23 -> 13 us; the look-ahead workgroup's chain load -> update -> invert is what a step waits for)
+template <int NP>
+__device__ inline bool gj_invert_halfrows(double (&prow)[NP / 2], int lane) {
+  constexpr int H = NP / 2;
+  const int r = lane & 31, h = lane >> 5;
+  bool spd = true;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int hk = k / H, kk = k % H;
+    double pk[H];
+#pragma unroll
+    for (int c = 0; c < H; ++c) pk[c] = __shfl(prow[c], k + 32 * h);
+    const double pkk = __shfl(prow[kk], k + 32 * hk);
+    if (!(pkk > 0.0)) spd = false;
+    const double d = 1.0 / pkk;
+    const double f = __shfl(prow[kk], r + 32 * hk);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const double rk = pk[j] * d;  // scaled pivot row
+      const bool pivcol = j == kk && h == hk;
+      if (r == k) prow[j] = pivcol ? d : rk;
+      else prow[j] = pivcol ? -f * d : prow[j] - f * rk;
+    }
+  }
+  return spd;
+}
+
+// the NP x NP block at src (row stride ld) -> its inverse in Pout (NP x NP, dense), by one wavefront
+template <int NP>
+__device__ inline void gj_invert_block(const double* src, int ld, double* __restrict__ Pout, int lane,
+                                       DevScalars* sc) {
+  bool spd;
+  if constexpr (NP % 2 == 0) {
+    constexpr int H = NP / 2;
+    double prow[H];
+    const int r = lane & 31, h = lane >> 5, rr = r < NP ? r : 0;
+#pragma unroll
+    for (int c = 0; c < H; ++c) prow[c] = src[(size_t)rr * ld + H * h + c];
+    spd = gj_invert_halfrows<NP>(prow, lane);
+    if (r < NP) {
+#pragma unroll
+      for (int c = 0; c < H; ++c) Pout[r * NP + H * h + c] = prow[c];
+    }
+  } else {
+    double prow[NP];
+    const int rr = lane < NP ? lane : 0;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) prow[c] = src[(size_t)rr * ld + c];
+    spd = gj_invert_rows<NP>(prow, lane);
+    if (lane < NP) {
+#pragma unroll
+      for (int c = 0; c < NP; ++c) Pout[lane * NP + c] = prow[c];
+    }
+  }
+  if (!spd && lane == 0) sc->fail = 1;
+}
+
+// the first pivot block's inverse (one wavefront)
 template <int PB>
-__global__ __launch_bounds__(WG) void k_amg_dense_gj_step(int n, int k0, const double* __restrict__ A,
-                                                          double* __restrict__ B, DevScalars* sc) {
+__global__ __launch_bounds__(64) void k_amg_dense_gj_first(int n, const double* __restrict__ A,
+                                                           double* __restrict__ Pout, DevScalars* sc) {
+  gj_invert_block<PB>(A, n, Pout, threadIdx.x, sc);
+}
+
+// pbn = rows of the next pivot block (<= PB; 0: this is the last step).  Two workgroups per CU (<= 256 VGPRs:
+// the tile grid of 1141 unknowns is 324 workgroups, a little more than one per CU)
+template <int PB>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void k_amg_dense_gj_step(int n, int k0, const double* __restrict__ A,
+                                                          double* __restrict__ B,
+                                                          const double* __restrict__ Pin,
+                                                          double* __restrict__ Pout, int pbn,
+                                                          DevScalars* sc) {
   __shared__ double P[PB][PB + 1];
-  __shared__ double ak[PB][64];       // pivot rows A_k. for the tile's columns
+  __shared__ double ak[PB][64];       // pivot rows A_k. for the tile's columns (look-ahead: then the updated next pivot block)
   __shared__ double rowk[PB][64];     // (P A_k.) for the tile's columns
   __shared__ double colk[64][PB + 1]; // A_.k for the tile's rows
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  // every global read of the set-up is issued before anything waits: one memory round trip
-  double prow[PB];  // wavefront 0: lane i < PB holds row i of the pivot block
-  if (tid < 64) {
-    const int rr = lane < PB ? lane : 0;
+  const int tid = threadIdx.x;
+  const bool ahead = blockIdx.y == 0;
+  if (ahead && (blockIdx.x != 0 || pbn == 0)) return;
+  // the look-ahead workgroup's "tile" is the next pivot block
+  const int ext = ahead ? pbn : 64;
+  const int i0 = ahead ? k0 + PB : (int)(blockIdx.y - 1) * 64, j0 = ahead ? k0 + PB : (int)blockIdx.x * 64;
+  // every global read is issued before anything waits -- the tile itself included (a thread owns the 4 x 4
+  // elements (ty + 16 a, tx + 16 b): 128-byte row segments per 16 lanes): one memory round trip per step
+  const int ty = tid >> 4, tx = tid & 15;
+  double v[4][4];
+  if (ahead) {  // (at most 28 x 28 = 784 elements: 4 per thread, element t = tid + 256 e)
 #pragma unroll
-    for (int c = 0; c < PB; ++c) prow[c] = A[(size_t)(k0 + rr) * n + k0 + c];
+    for (int e = 0; e < 4; ++e) {
+      const int t = tid + WG * e;
+      v[0][e] = t < ext * ext ? A[(size_t)(i0 + t / ext) * n + j0 + t % ext] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+        v[a][b] = i < n && j < n ? A[(size_t)i * n + j] : 0.0;
+      }
   }
-  for (int t = tid; t < 64 * PB; t += WG) {
+  for (int t = tid; t < PB * PB; t += WG) P[t / PB][t % PB] = Pin[t];
+  for (int t = tid; t < ext * PB; t += WG) {
     const int i = t / PB, m = t % PB;
     colk[i][m] = i0 + i < n ? A[(size_t)(i0 + i) * n + k0 + m] : 0.0;
   }
   for (int t = tid; t < PB * 64; t += WG) {
     const int q = t / 64, j = t % 64;
-    ak[q][j] = j0 + j < n ? A[(size_t)(k0 + q) * n + j0 + j] : 0.0;
-  }
-  if (tid < 64) {  // in-place Gauss-Jordan inverse of the pivot block
-    bool spd = true;
-#pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      double pk[PB];
-#pragma unroll
-      for (int c = 0; c < PB; ++c) pk[c] = __shfl(prow[c], k);
-      if (!(pk[k] > 0.0)) spd = false;
-      const double d = 1.0 / pk[k];
-      const double f = prow[k];
-#pragma unroll
-      for (int j = 0; j < PB; ++j) {
-        const double rk = pk[j] * d;  // scaled pivot row
-        if (lane == k) prow[j] = j == k ? d : rk;
-        else prow[j] = j == k ? -f * d : prow[j] - f * rk;
-      }
-    }
-    if (lane < PB) {
-#pragma unroll
-      for (int c = 0; c < PB; ++c) P[lane][c] = prow[c];
-    }
-    if (!spd && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) sc->fail = 1;
+    ak[q][j] = j < ext && j0 + j < n ? A[(size_t)(k0 + q) * n + j0 + j] : 0.0;
   }
   __syncthreads();
-  for (int t = tid; t < PB * 64; t += WG) {  // (P A_k.) slice
-    const int m = t / 64, j = t % 64;
+  // R = P A_k. for the tile's columns; in the pivot columns themselves R = P, which turns the four cases of
+  // the update into one:  B_ij = R_(i-k0)j on pivot rows, else (A_ij, or 0 in a pivot column) - sum_m A_im R_mj
+  for (int t = tid; t < PB * 64; t += WG) {
+    const int m = t / 64, j = t % 64, jp = j0 + j - k0;
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < PB; ++q) acc += P[m][q] * ak[q][j];
-    rowk[m][j] = acc;
+    rowk[m][j] = jp >= 0 && jp < PB ? P[m][jp] : acc;
   }
   __syncthreads();
-  for (int t = tid; t < 64 * 64; t += WG) {
-    const int il = t / 64, jl = t % 64, i = i0 + il, j = j0 + jl;
-    if (i >= n || j >= n) continue;
-    const bool ik = i >= k0 && i < k0 + PB, jk = j >= k0 && j < k0 + PB;
-    double v;
-    if (ik && jk) {
-      v = P[i - k0][j - k0];
-    } else if (ik) {
-      v = rowk[i - k0][jl];
-    } else if (jk) {
-      v = 0.0;
+  if (ahead) {
+    // (no row or column of the next pivot block lies in the current one)
 #pragma unroll
-      for (int m = 0; m < PB; ++m) v -= colk[il][m] * P[m][j - k0];
-    } else {
-      v = A[(size_t)i * n + j];
+    for (int e = 0; e < 4; ++e) {
+      const int t = tid + WG * e;
+      if (t < ext * ext) {
+        const int il = t / ext, jl = t % ext;
+        double w = v[0][e];
 #pragma unroll
-      for (int m = 0; m < PB; ++m) v -= colk[il][m] * rowk[m][jl];
+        for (int m = 0; m < PB; ++m) w -= colk[il][m] * rowk[m][jl];
+        ak[il][jl] = w;
+      }
     }
-    B[(size_t)i * n + j] = v;
+    __syncthreads();
+    if (tid < 64) {
+      if (pbn == PB) gj_invert_block<PB>(&ak[0][0], 64, Pout, tid, sc);
+      else if (pbn == 14) gj_invert_block<14>(&ak[0][0], 64, Pout, tid, sc);
+      else gj_invert_block<7>(&ak[0][0], 64, Pout, tid, sc);
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int jp = j0 + tx + 16 * b - k0;
+    if (jp >= 0 && jp < PB) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) v[a][b] = 0.0;
+    }
+  }
+#pragma unroll 7
+  for (int m = 0; m < PB; ++m) {
+    double cm[4], rm[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cm[a] = colk[ty + 16 * a][m];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rm[b] = rowk[m][tx + 16 * b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[a][b] -= cm[a] * rm[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + ty + 16 * a, ip = i - k0;
+    const bool ik = ip >= 0 && ip < PB;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int jl = tx + 16 * b, j = j0 + jl;
+      if (i < n && j < n) B[(size_t)i * n + j] = ik ? rowk[ip][jl] : v[a][b];
+    }
   }
 }
 

@@ -144,7 +144,7 @@ class Engine {
   };
   std::vector<AmgLevel> amg;
   std::vector<void*> amg_owned;
-  double *d_P = nullptr, *d_Ainv = nullptr, *d_Ainv2 = nullptr, *d_az = nullptr;
+  double *d_P = nullptr, *d_Ainv = nullptr, *d_Ainv2 = nullptr, *d_piv = nullptr, *d_az = nullptr;
   int32_t* d_row2v = nullptr;
   bool use_amg = false, amg_stale = true;
   double amg_omega = 0.9;  // damping of the block-Jacobi smoother: eig(D^-1 A) <= 2 on every level
@@ -627,6 +627,7 @@ class Engine {
     const size_t nc = (size_t)7 * amg[nl - 1].nb;
     AMGCHK(amg_alloc(d_Ainv, nc * nc, err));
     AMGCHK(amg_alloc(d_Ainv2, nc * nc, err));
+    AMGCHK(amg_alloc(d_piv, 2 * 28 * 28, err));  // pivot-block inverses handed from step to step
 #undef AMGCHK
     if (opt.verbose) {
       std::fprintf(stderr, "sim3opt: multigrid levels (rows/blocks):");
@@ -693,35 +694,39 @@ class Engine {
     // dense inverse of the coarsest level: one launch per 14-row pivot block, buffers ping-pong
     const AmgLevel& Lc = amg[nl - 1];
     const int nd = 7 * Lc.nb;
-    (void)hipMemsetAsync(d_Ainv2, 0, sizeof(double) * (size_t)nd * nd, stream);
-    hipLaunchKernelGGL(k_amg_dense_fill, dim3(grid_for(49 * Lc.nnzb, WG)), dim3(WG), 0, stream, Lc.nb,
-                       Lc.rowptr, Lc.colidx, Lc.vals, d_Ainv2);
-    // pivot blocks of `amg_pivot` rows (14: 82 launches of 23 us for 1141 unknowns; 28: 41 of 47 us), then
-    // 14, then 7 for the tail; an even number of steps would end in d_Ainv2: start from d_Ainv then
-    // (round 3: 32-row pivots inverted by the whole workgroup in LDS took 36 x 52 us -- the same 1.9 ms;
-    // profiles/r3_negative_results.log)
+    // pivot blocks of `amg_pivot` rows (14: 82 launches for 1141 unknowns), then 14, then 7 for the tail; the
+    // buffers ping-pong and the last step must write d_Ainv, which fixes the buffer the matrix is filled into
+    // (round 3: 32-row pivots inverted by the whole workgroup in LDS took 36 x 52 us -- the same 1.9 ms as 82 x
+    // 23 us; profiles/r3_negative_results.log.  What did pay is taking the pivot inverse off each step's
+    // critical path: k_amg_dense_gj_step's look-ahead workgroup)
+    auto pivot_rows = [&](int k0) { return nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7); };
     int nsteps = 0;
-    for (int k0 = 0; k0 < nd;) { k0 += nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7); ++nsteps; }
-    double *src = d_Ainv2, *dst = d_Ainv;
-    if (nsteps % 2 == 0) {
-      (void)hipMemcpyAsync(d_Ainv, d_Ainv2, sizeof(double) * (size_t)nd * nd, hipMemcpyDeviceToDevice, stream);
-      src = d_Ainv;
-      dst = d_Ainv2;
+    for (int k0 = 0; k0 < nd; k0 += pivot_rows(k0)) ++nsteps;
+    double *src = nsteps % 2 ? d_Ainv2 : d_Ainv, *dst = nsteps % 2 ? d_Ainv : d_Ainv2;
+    (void)hipMemsetAsync(src, 0, sizeof(double) * (size_t)nd * nd, stream);
+    hipLaunchKernelGGL(k_amg_dense_fill, dim3(grid_for(49 * Lc.nnzb, WG)), dim3(WG), 0, stream, Lc.nb,
+                       Lc.rowptr, Lc.colidx, Lc.vals, src);
+    double *pin = d_piv, *pout = d_piv + 28 * 28;
+    switch (pivot_rows(0)) {
+      case 28: hipLaunchKernelGGL((k_amg_dense_gj_first<28>), dim3(1), dim3(64), 0, stream, nd, (const double*)src, pin, d_sc); break;
+      case 14: hipLaunchKernelGGL((k_amg_dense_gj_first<14>), dim3(1), dim3(64), 0, stream, nd, (const double*)src, pin, d_sc); break;
+      default: hipLaunchKernelGGL((k_amg_dense_gj_first<7>), dim3(1), dim3(64), 0, stream, nd, (const double*)src, pin, d_sc);
     }
-    const dim3 gt((nd + 63) / 64, (nd + 63) / 64);
+    const dim3 gt((nd + 63) / 64, (nd + 63) / 64 + 1);  // row 0 of the grid: the look-ahead workgroup
     for (int k0 = 0; k0 < nd;) {
-      const int pb = nd - k0 >= amg_pivot ? amg_pivot : (nd - k0 >= 14 ? 14 : 7);
+      const int pb = pivot_rows(k0), pbn = k0 + pb < nd ? pivot_rows(k0 + pb) : 0;
       if (pb == 28)
         hipLaunchKernelGGL((k_amg_dense_gj_step<28>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
-                           dst, d_sc);
+                           dst, (const double*)pin, pout, pbn, d_sc);
       else if (pb == 14)
         hipLaunchKernelGGL((k_amg_dense_gj_step<14>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
-                           dst, d_sc);
+                           dst, (const double*)pin, pout, pbn, d_sc);
       else
         hipLaunchKernelGGL((k_amg_dense_gj_step<7>), gt, dim3(WG), 0, stream, nd, k0, (const double*)src,
-                           dst, d_sc);
+                           dst, (const double*)pin, pout, pbn, d_sc);
       k0 += pb;
       std::swap(src, dst);
+      std::swap(pin, pout);
     }  // the inverse is in d_Ainv
   }
 

@@ -37,8 +37,9 @@
 constexpr bool FASTPATH = SIM3OPT_SPMV_FASTPATH != 0;
 template <int CH, bool NT, int MODE, typename VT = double>
 __global__ __launch_bounds__(WG)
-// (the FP32 smoothing pass also carries the r.z partial now: keep it at 6 wavefronts per SIMD, 80 VGPRs)
-__attribute__((amdgpu_waves_per_eu(sizeof(VT) == 4 && MODE == 2 && CH == 8 ? 6 : 1))) void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
+// (no occupancy floor: the FP32 smoothing pass at 88 VGPRs / 5 wavefronts per SIMD without spills runs 0.5-1 %
+// faster end to end than forced to 80 VGPRs / 6 wavefronts with 3-5 spilled registers; r3_negative_results.log)
+void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
                                                   const VT* __restrict__ vals,
