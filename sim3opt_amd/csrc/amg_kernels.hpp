@@ -54,7 +54,7 @@ __global__ __launch_bounds__(WG) void k_amg_adjoint(int nb, const int32_t* __res
 // Coarse block cb = sum over its fine blocks k (row i, column j) of P_i^T A_k P_j, in list order.
 // One wavefront per coarse block; the two 7x7x7 products run on the LDS crossbar (ds_bpermute).
 // Every fine block is read exactly once here, so the FP32 copy the cycle's matrix passes stream
-// (vals32_f, may be null) is written on the way.  Four fine blocks (and their P_i, P_j) in flight.
+// (vals32_f, may be null) is written on the way.
 template <bool HASP>
 __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ gblk,
@@ -71,60 +71,69 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
   const int r = l49 % 7, c = l49 / 7;
   double acc = 0.0;
   const int e0 = gptr[cb], e1 = gptr[cb + 1];
-  if (HASP) {
-    // The operands of the two products that exist in memory -- column c of P_j, column r of P_i --
-    // are loaded in the layout the lane needs them in (seven consecutive doubles each, from lines
-    // the cache holds); only A and T = A P_j go through the LDS crossbar.  With all four operands
-    // shuffled the kernel was bound by that crossbar (56 ds_bpermute per fine block); the texture
-    // path was idle.  Same products in the same order: bit-identical results.
-    constexpr int GF = 1;
-    for (int e = e0; e < e1; e += GF) {
-      const int m = e1 - e < GF ? e1 - e : GF;
-      int kk[GF];
-      double av[GF], pj[GF][7], pi[GF][7];
+  // The lists of a coarse block arrive by vector loads, one entry per lane (64 at a time; an aggregate of 8
+  // rows has at most 64 fine blocks) -- fine block, its row's and its column's vertex -- so that the operand
+  // loads of every fine block are independent of everything but those: the kernel is a chain of memory round
+  // trips per wavefront, and with an index chain in front of every block it ran three per fine block
+  // (0.98 ms per linearisation on config 3; round 3).
+  for (int eb = e0; eb < e1; eb += 64) {
+    const int n = e1 - eb < 64 ? e1 - eb : 64;
+    const int le = lane < n ? lane : n - 1;
+    const int kkv = gblk[eb + le];
+    if (HASP) {
+      // The operands of the two products that exist in memory -- column c of P_j, column r of P_i --
+      // are loaded in the layout the lane needs them in (seven consecutive doubles each, from lines
+      // the cache holds); only A and T = A P_j go through the LDS crossbar.  With all four operands
+      // shuffled the kernel was bound by that crossbar (56 ds_bpermute per fine block); the texture
+      // path was idle.  Two fine blocks' operands in flight.  Same products in the same order as ever:
+      // bit-identical results.
+      const int giv = grow[eb + le];
+      const int cjv = colidx_f[kkv];
+      double av[2], pj[2][7], pi[2][7];
+      int kk[2];
+      auto load = [&](int u, int b) {
+        kk[b] = __builtin_amdgcn_readlane(kkv, u);
+        av[b] = vals_f[(size_t)49 * kk[b] + l49];
+        const double* pjp = P + (size_t)49 * __builtin_amdgcn_readlane(cjv, u) + 7 * c;
+        const double* pip = P + (size_t)49 * __builtin_amdgcn_readlane(giv, u) + 7 * r;
 #pragma unroll
-      for (int u = 0; u < GF; ++u)
-        if (u < m) {
-          kk[u] = gblk[e + u];
-          av[u] = vals_f[(size_t)49 * kk[u] + l49];
-          const double* pjp = P + (size_t)49 * colidx_f[kk[u]] + 7 * c;
-          const double* pip = P + (size_t)49 * grow[e + u] + 7 * r;
+        for (int q = 0; q < 7; ++q) {
+          pj[b][q] = pjp[q];
+          pi[b][q] = pip[q];
+        }
+      };
+      auto consume = [&](int b) {
+        if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[b], lane)] = (float)av[b];
+        double t = 0.0;  // T = A P_j
 #pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            pj[u][q] = pjp[q];
-            pi[u][q] = pip[q];
+        for (int q = 0; q < 7; ++q) t += __shfl(av[b], r + 7 * q) * pj[b][q];
+        double o = 0.0;  // P_i^T T
+#pragma unroll
+        for (int q = 0; q < 7; ++q) o += pi[b][q] * __shfl(t, q + 7 * c);
+        acc += o;
+      };
+      for (int u = 0; u < n; ++u) {
+        load(u, 0);
+        consume(0);
+      }
+    } else {
+      for (int u0 = 0; u0 < n; u0 += 4) {
+        const int m = n - u0 < 4 ? n - u0 : 4;
+        int kk[4];
+        double av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < m) {
+            kk[u] = __builtin_amdgcn_readlane(kkv, u0 + u);
+            av[u] = vals_f[(size_t)49 * kk[u] + l49];
           }
-        }
 #pragma unroll
-      for (int u = 0; u < GF; ++u)
-        if (u < m) {
-          if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
-          double t = 0.0;  // T = A P_j
-#pragma unroll
-          for (int q = 0; q < 7; ++q) t += __shfl(av[u], r + 7 * q) * pj[u][q];
-          double o = 0.0;  // P_i^T T
-#pragma unroll
-          for (int q = 0; q < 7; ++q) o += pi[u][q] * __shfl(t, q + 7 * c);
-          acc += o;
-        }
-    }
-  } else {
-    for (int e = e0; e < e1; e += 4) {
-      const int m = e1 - e < 4 ? e1 - e : 4;
-      int kk[4];
-      double av[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u < m) {
-          kk[u] = gblk[e + u];
-          av[u] = vals_f[(size_t)49 * kk[u] + l49];
-        }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u < m) {
-          if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
-          acc += av[u];
-        }
+        for (int u = 0; u < 4; ++u)
+          if (u < m) {
+            if (vals32_f && lane < 49) vals32_f[f32_pair_index(kk[u], lane)] = (float)av[u];
+            acc += av[u];
+          }
+      }
     }
   }
   if (lane < 49) vals_c[(size_t)49 * cb + lane] = acc;
