@@ -222,7 +222,7 @@ class Engine {
     void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                     d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
                     d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
-                    d_sub_first, d_sub_cnt, d_Gm, d_brow, d_halo};
+                    d_sub_first, d_sub_cnt, d_Gm, d_brow, d_halo, d_ptab};
     for (void* p : ptrs)
       if (p) dev_free(p);
     for (void* p : amg_owned)
@@ -1004,10 +1004,23 @@ class Engine {
     return SIM3OPT_OK;
   }
 
+  // the perturbation table of the numeric Jacobians, re-evaluated when delta or the arithmetic options change
+  Sim3* d_ptab = nullptr;
+  double ptab_delta = 0.0;
+  sim3::Opts ptab_opts{0.0, -1, -1};
+
   int linearize(std::string& err) {
+    const sim3::Opts mo = mopts();
+    if (!d_ptab) HIPCHK(dev_malloc((void**)&d_ptab, 14 * sizeof(Sim3)));
+    if (ptab_delta != opt.fd_delta || ptab_opts.eps != mo.eps || ptab_opts.small_rot_half != mo.small_rot_half ||
+        ptab_opts.fix_small_b != mo.fix_small_b) {
+      hipLaunchKernelGGL(k_perturbation_table, dim3(1), dim3(64), 0, stream, opt.fd_delta, mo, d_ptab);
+      ptab_delta = opt.fd_delta;
+      ptab_opts = mo;
+    }
     LinArgs A{n_active, d_active, d_ev0, d_ev1, d_meas, d_info, d_kdelta, d_states,
-              d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mopts(),
-              opt.dof_mask, d_sc};
+              d_slot01, d_slot10, d_inc0, d_inc1, d_vals, d_scratch, opt.fd_delta, mo,
+              (const Sim3*)d_ptab, opt.dof_mask, d_sc};
     const int g = (n_active + EPB - 1) / EPB;
     if (g == 0) HIPCHK(hipMemsetAsync(&d_sc->maxdiag_bits, 0, sizeof(unsigned long long), stream));
     if (g > 0) {

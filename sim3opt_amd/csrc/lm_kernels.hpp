@@ -182,6 +182,7 @@ struct LinArgs {
   double* scratch;
   double delta;
   sim3::Opts opts;
+  const Sim3* ptab;  // exp(+-delta e_d), entry 2 d + (0: +, 1: -)  (k_perturbation_table)
   int32_t dof_mask;  // cleared bit d: Jacobian column d of both endpoints is zero (frozen DoF)
   DevScalars* sc;    // max |H_dd| starts from zero here (k_diag_reduce, the next launch, raises it)
 };
@@ -193,6 +194,20 @@ struct GramTables {
 __constant__ GramTables c_tab;
 
 constexpr int EPB = 8;  // edges per workgroup
+
+// The 14 perturbations exp(+-delta e_d) of the numeric Jacobians are the same for every edge: evaluated
+// once (the same sim3::exp on the same arguments: bit-identical to evaluating it per lane) instead of
+// 28 times per edge and linearisation -- a quarter of k_linearize_numeric's arithmetic.
+__global__ __launch_bounds__(64) void k_perturbation_table(double delta, sim3::Opts opts, Sim3* __restrict__ tab) {
+  const int t = threadIdx.x;
+  if (t >= 14) return;
+  const int d = t >> 1;
+  const double step = (t & 1) ? -delta : delta;
+  double xi[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xi[i] = (i == d) ? step : 0.0;
+  tab[t] = sim3::exp(xi, opts);
+}
 
 template <bool HAS_INFO, bool HAS_KERNEL>
 __global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
@@ -224,12 +239,7 @@ __global__ __launch_bounds__(WG) void k_linearize_numeric(LinArgs A) {
     S1.q[0] = in[16]; S1.q[1] = in[17]; S1.q[2] = in[18]; S1.q[3] = in[19];
     S1.t[0] = in[20]; S1.t[1] = in[21]; S1.t[2] = in[22]; S1.s = in[23];
     if (l < 28) {
-      const int d = (l % 14) >> 1;
-      const double step = (l & 1) ? -A.delta : A.delta;
-      double xi[7];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) xi[i] = (i == d) ? step : 0.0;
-      const Sim3 P = sim3::exp(xi, A.opts);
+      const Sim3 P = A.ptab[l % 14];  // direction (l % 14) / 2, sign by the parity of l
       if (l < 14) S0 = sim3::mul(P, S0);
       else S1 = sim3::mul(P, S1);
     }
