@@ -2,6 +2,7 @@
 #include "direct.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace sim3opt {
@@ -184,42 +185,63 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
     return false;
   }
   // ---- groups: bottom subtrees of <= tau columns are independent; the rest is the top ----
-  const int32_t tau = subtree_cols > 0 ? subtree_cols : std::max(4, nb / 48);
+  // (automatic: a sixteenth of the columns, at most 64 -- a level costs a bottom group half of what it costs
+  // the top group, whose early levels are wide; KITTI-00: 48 columns, 215 / 387 us per solve against 256 / 465 us
+  // with 16 columns and four wavefronts per group; profiles/r3_direct_sweep.log)
+  if (subtree_cols <= 0)
+    if (const char* ev = std::getenv("SIM3OPT_DIRECT_SUBTREE")) subtree_cols = std::atoi(ev);  // tuning knob
+  const int32_t tau = subtree_cols > 0 ? subtree_cols : std::max(4, std::min(64, nb / 16));
   std::vector<int32_t> size(nb, 1);
   for (int32_t j = 0; j < nb; ++j)
     if (parent[j] >= 0) size[parent[j]] += size[j];
   std::vector<int32_t> group(nb, -1), level(nb, 0);
-  const bool single = nb <= 2 * tau;
-  int32_t ng = 0;
-  if (!single) {
-    // roots of bottom subtrees in elimination order; consecutive ones share a group up to tau columns
-    int32_t fill = 0;
-    for (int32_t j = 0; j < nb; ++j) {
-      if (size[j] > tau) continue;
-      const int32_t p = parent[j];
-      if (p >= 0 && size[p] <= tau) continue;  // not a subtree root
-      if (fill == 0 || fill + size[j] > tau) { ++ng; fill = 0; }
-      group[j] = ng - 1;
-      fill += size[j];
+  // columns (positions of the dissection order) sorted by (group, level, position) for subtrees of <= t columns
+  auto schedule_order = [&](int32_t t, std::vector<int32_t>& idx) {
+    group.assign(nb, -1);
+    level.assign(nb, 0);
+    const bool single = nb <= 2 * t;
+    int32_t ng = 0;
+    if (!single) {
+      // roots of bottom subtrees in elimination order; consecutive ones share a group up to t columns
+      int32_t fill = 0;
+      for (int32_t j = 0; j < nb; ++j) {
+        if (size[j] > t) continue;
+        const int32_t p = parent[j];
+        if (p >= 0 && size[p] <= t) continue;  // not a subtree root
+        if (fill == 0 || fill + size[j] > t) { ++ng; fill = 0; }
+        group[j] = ng - 1;
+        fill += size[j];
+      }
+      // descendants inherit the group of their subtree root (parents have larger indices)
+      for (int32_t j = nb - 1; j >= 0; --j)
+        if (group[j] < 0 && size[j] <= t) group[j] = group[parent[j]];
     }
-    // descendants inherit the group of their subtree root (parents have larger indices)
-    for (int32_t j = nb - 1; j >= 0; --j)
-      if (group[j] < 0 && size[j] <= tau) group[j] = group[parent[j]];
-  }
-  const int32_t top = ng;  // the last group
-  for (int32_t j = 0; j < nb; ++j)
-    if (group[j] < 0) group[j] = top;
-  for (int32_t j = 0; j < nb; ++j) {  // level = height among children of the same group
-    const int32_t p = parent[j];
-    if (p >= 0 && group[p] == group[j]) level[p] = std::max(level[p], level[j] + 1);
-  }
+    const int32_t top = ng;  // the last group
+    for (int32_t j = 0; j < nb; ++j)
+      if (group[j] < 0) group[j] = top;
+    for (int32_t j = 0; j < nb; ++j) {  // level = height among children of the same group
+      const int32_t p = parent[j];
+      if (p >= 0 && group[p] == group[j]) level[p] = std::max(level[p], level[j] + 1);
+    }
+    idx.resize(nb);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+      if (group[a] != group[b]) return group[a] < group[b];
+      return level[a] < level[b];
+    });
+  };
+  // The ORDER OF SUMMATION (products of a block, rows of a backward-solve column) is that of a reference
+  // numbering -- the schedule of round 2, subtrees of nb / 48 columns -- whatever schedule runs: every
+  // schedule is a topological order of the same elimination tree, so the blocks of L are the same numbers
+  // and, summed in one fixed order, the same bits.  Tuning the schedule does not move a chaotic LM run.
+  std::vector<int32_t> idx_ref, idx;
+  schedule_order(std::max(4, nb / 48), idx_ref);
+  std::vector<int32_t> refpos(nb);  // dissection position -> reference position
+  for (int32_t r = 0; r < nb; ++r) refpos[idx_ref[r]] = r;
   // ---- renumber by (group, level, position): every level becomes a contiguous column range ----
-  std::vector<int32_t> idx(nb);
-  std::iota(idx.begin(), idx.end(), 0);
-  std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
-    if (group[a] != group[b]) return group[a] < group[b];
-    return level[a] < level[b];
-  });
+  schedule_order(tau, idx);
+  std::vector<int32_t> key(nb);  // final column -> reference position
+  for (int32_t j = 0; j < nb; ++j) key[j] = refpos[idx[j]];
   P.nb = nb;
   P.perm.resize(nb);
   for (int32_t j = 0; j < nb; ++j) P.perm[j] = D.order[idx[j]];
@@ -302,6 +324,8 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
     }
   }
   // ---- update lists: column k contributes L(i,k) L(j,k)^T to every block (i,j), j <= i in its rows ----
+  std::vector<int32_t> by_key(nb);
+  for (int32_t j = 0; j < nb; ++j) by_key[key[j]] = j;
   P.pairptr.assign(P.nL + 1, 0);
   for (int pass = 0; pass < 2; ++pass) {
     std::vector<int32_t> cur;
@@ -312,7 +336,8 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
       P.pcol.resize(P.pairptr[P.nL]);
       cur.assign(P.pairptr.begin(), P.pairptr.end() - 1);
     }
-    for (int32_t k = 0; k < nb; ++k) {
+    for (int32_t kr = 0; kr < nb; ++kr) {  // (ascending reference position of the source column)
+      const int32_t k = by_key[kr];
       const std::vector<int32_t>& c = cols[k];
       const int32_t base = P.colptr[k] + 1;
       for (size_t a = 0; a < c.size(); ++a)
@@ -328,6 +353,16 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
           }
         }
     }
+  }
+  // ---- backward solve: the blocks of a column in ascending reference position of their rows ----
+  P.bord.resize(P.nL);
+  P.brow.resize(P.nL);
+  for (int32_t j = 0; j < nb; ++j) {
+    const int32_t s0 = P.colptr[j], s1 = P.colptr[j + 1];
+    for (int32_t t = s0; t < s1; ++t) P.bord[t] = t;
+    std::sort(P.bord.begin() + s0 + 1, P.bord.begin() + s1,
+              [&](int32_t x, int32_t y) { return key[P.lrow[x]] < key[P.lrow[y]]; });
+    for (int32_t t = s0; t < s1; ++t) P.brow[t] = P.lrow[P.bord[t]];
   }
   // ---- work split: rounds of cells per level (see direct.hpp) ----
   {

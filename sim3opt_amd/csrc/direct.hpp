@@ -38,8 +38,11 @@ struct DirectPlan {
   std::vector<int32_t> srcptr;    // nL + 1 -> src: blocks of H (indices into the block-CSR values)
   std::vector<int32_t> src;       //   summed into this block of L (parallel edges: several; fill: none)
   std::vector<int32_t> pairptr;   // nL + 1 -> pa/pb: products L[pa] L[pb]^T subtracted from this
-  std::vector<int32_t> pa, pb;    //   block, ascending source column
+  std::vector<int32_t> pa, pb;    //   block, in ascending REFERENCE position of the source column (direct.cpp)
   std::vector<int32_t> pcol;      //   ... and that source column k (the forward solve rides along)
+  std::vector<int32_t> bord;      // nL: backward solve of column j visits its blocks bord[colptr[j] + 1 ...]
+  std::vector<int32_t> brow;      //   ... whose rows are brow[same index] (a fixed order of summation that
+                                  //   does not depend on the schedule; direct.cpp)
   // schedule: group g runs levels [gptr[g], gptr[g+1]); level l is columns [lcolp[l], lcolp[l+1]).
   // The last group is the top of the tree (everything the others feed into).
   std::vector<int32_t> gptr;
@@ -51,7 +54,7 @@ struct DirectPlan {
   // everything it needs to issue its index loads.  Bottom groups run `sub_waves` wavefronts, the top
   // group CELL_WAVES.
   static constexpr int CELL_WAVES = 8, CELL_SLOTS = 8, CELL_STRIDE = 2 * (CELL_WAVES + 1);
-  int32_t sub_waves = 4;
+  int32_t sub_waves = 8;
   std::vector<int32_t> rptr;
   std::vector<int32_t> cells;
   int32_t ngroups() const { return (int32_t)gptr.size() - 1; }
@@ -64,6 +67,6 @@ struct DirectPlan {
 // (<= 0: automatic).
 // sub_waves: wavefronts per workgroup of the bottom groups (1 .. CELL_WAVES).
 bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int64_t max_pairs,
-                       int32_t subtree_cols, DirectPlan& plan, std::string& why, int32_t sub_waves = 4);
+                       int32_t subtree_cols, DirectPlan& plan, std::string& why, int32_t sub_waves = 8);
 
 }  // namespace sim3opt

@@ -36,6 +36,8 @@ struct LdlArgs {
   const int32_t* pcol;
   const int32_t* gptr;
   const int32_t* lcolp;
+  const int32_t* bord;
+  const int32_t* brow;
   const int32_t* rptr;
   const int32_t* cells;
   const double* vals;  // block-CSR values of H (column-major 7x7)
@@ -55,7 +57,7 @@ struct LdlArgs {
 
 constexpr int LDL_WG_TOP = 64 * DirectPlan::CELL_WAVES;  // the top of the tree: one workgroup of 8
 // wavefronts (512 threads leave each wavefront 256 VGPRs: with 1024 the operand batches spilled)
-constexpr int LDL_WG_SUB = 256;                          // bottom subtrees: 4 wavefronts each
+constexpr int LDL_WG_SUB = 512;                          // bottom subtrees: 8 wavefronts each too (round 3 sweep)
 constexpr int LDL_CS = DirectPlan::CELL_SLOTS;
 constexpr int LDL_ST = DirectPlan::CELL_STRIDE;
 constexpr int LDL_NW = DirectPlan::CELL_WAVES;
@@ -153,14 +155,17 @@ __device__ __forceinline__ void ldl_back(const LdlArgs& A, int j, int lane, int 
   const double li = A.Dinv[(size_t)49 * j + l49];
   double t = 0.0;
   for (int sb = s0 + 1; sb < s1; sb += 64) {
-    const int vr = sb + lane < s1 ? A.lrow[sb + lane] : 0;  // rows of up to 64 blocks, one per lane
+    // up to 64 blocks, one per lane, in the plan's fixed order of summation (bord / brow: the same
+    // order under every schedule, direct.cpp)
+    const int vs = sb + lane < s1 ? A.bord[sb + lane] : 0;
+    const int vr = sb + lane < s1 ? A.brow[sb + lane] : 0;
     const int nn = s1 - sb < 64 ? s1 - sb : 64;
     for (int q = 0; q < nn; q += 8) {  // eight blocks (and their x rows) in flight
       double lv[8], xv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (q + i < nn) {
-          lv[i] = A.L[(size_t)49 * (sb + q + i) + l49];
+          lv[i] = A.L[(size_t)49 * __builtin_amdgcn_readlane(vs, q + i) + l49];
           xv[i] = A.xp[(size_t)7 * __builtin_amdgcn_readlane(vr, q + i) + r];
         }
 #pragma unroll

@@ -917,6 +917,8 @@ class Engine {
     DCHK(direct_up(ldl.pcol, dplan.pcol, err));
     DCHK(direct_up(ldl.gptr, dplan.gptr, err));
     DCHK(direct_up(ldl.lcolp, dplan.lcolp, err));
+    DCHK(direct_up(ldl.bord, dplan.bord, err));
+    DCHK(direct_up(ldl.brow, dplan.brow, err));
     DCHK(direct_up(ldl.rptr, dplan.rptr, err));
     DCHK(direct_up(ldl.cells, dplan.cells, err));
     ldl.nb = nb;

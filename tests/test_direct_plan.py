@@ -116,7 +116,7 @@ def test_plan_solves_like_dense(name):
     # of at most 8 blocks, and every cell knows its product range
     assert len(P["rptr"]) == P["nlevels"] + 1 and P["rptr"][-1] == P["nrounds"]
     for g in range(P["ngroups"]):
-        nw = 8 if g == P["ngroups"] - 1 else 4
+        nw = 8  # (bottom groups run 8 wavefronts too since round 3: DirectPlan::sub_waves)
         for l in range(P["gptr"][g], P["gptr"][g + 1]):
             S0, S1 = P["colptr"][P["lcolp"][l]], P["colptr"][P["lcolp"][l + 1]]
             nxt = S0
