@@ -752,13 +752,16 @@ struct Problem {
       std::string why;
       if (sim3opt::build_direct_plan(NC, rptr.data(), bcol.data(), max_pairs, subtree, dplan, why, ldl_wg_sub / 64)) {
         int32_t *pperm, *pcolptr, *plrow, *plcol, *psrcptr, *psrc, *ppairptr, *ppa, *ppb, *ppcol, *pgptr, *plcolp,
-            *prptr, *pcells, *pbord, *pbrow;
+            *prptr, *pcells, *pbord, *pbrow, *ptpre, *ptprey;
         BCHK(up(pperm, dplan.perm)); BCHK(up(pcolptr, dplan.colptr)); BCHK(up(plrow, dplan.lrow));
         BCHK(up(plcol, dplan.lcol)); BCHK(up(psrcptr, dplan.srcptr)); BCHK(up(psrc, dplan.src));
         BCHK(up(ppairptr, dplan.pairptr)); BCHK(up(ppa, dplan.pa)); BCHK(up(ppb, dplan.pb));
         BCHK(up(ppcol, dplan.pcol)); BCHK(up(pgptr, dplan.gptr)); BCHK(up(plcolp, dplan.lcolp));
         BCHK(up(prptr, dplan.rptr)); BCHK(up(pcells, dplan.cells));
         BCHK(up(pbord, dplan.bord)); BCHK(up(pbrow, dplan.brow));
+        BCHK(up(ptpre, dplan.tpre)); BCHK(up(ptprey, dplan.tprey));
+        ldl.tpre = ptpre; ldl.tprey = ptprey;
+        ldl.ntpre = (int32_t)dplan.tpre.size(); ldl.ntprey = (int32_t)dplan.tprey.size();
         ldl.perm = pperm; ldl.colptr = pcolptr; ldl.lrow = plrow; ldl.lcol = plcol; ldl.srcptr = psrcptr;
         ldl.src = psrc; ldl.pairptr = ppairptr; ldl.pa = ppa; ldl.pb = ppb; ldl.pcol = ppcol; ldl.gptr = pgptr;
         ldl.lcolp = plcolp; ldl.rptr = prptr; ldl.cells = pcells; ldl.bord = pbord; ldl.brow = pbrow;

@@ -354,6 +354,20 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
         }
     }
   }
+  // ---- what the top group reads of the bottom groups' results (its warm-up touches them once, in bulk) ----
+  if (P.ngroups() > 1) {
+    const int32_t c0 = P.lcolp[P.gptr[P.ngroups() - 1]];  // first column of the top group
+    const int32_t s0 = P.colptr[c0];
+    for (int64_t k = P.pairptr[s0]; k < P.pairptr[P.nL]; ++k) {
+      if (P.pa[k] < s0) P.tpre.push_back(P.pa[k]);
+      if (P.pb[k] < s0) P.tpre.push_back(P.pb[k]);
+      if (P.pcol[k] < c0) P.tprey.push_back(P.pcol[k]);
+    }
+    std::sort(P.tpre.begin(), P.tpre.end());
+    P.tpre.erase(std::unique(P.tpre.begin(), P.tpre.end()), P.tpre.end());
+    std::sort(P.tprey.begin(), P.tprey.end());
+    P.tprey.erase(std::unique(P.tprey.begin(), P.tprey.end()), P.tprey.end());
+  }
   // ---- backward solve: the blocks of a column in ascending reference position of their rows ----
   P.bord.resize(P.nL);
   P.brow.resize(P.nL);

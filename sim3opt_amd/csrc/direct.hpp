@@ -40,6 +40,8 @@ struct DirectPlan {
   std::vector<int32_t> pairptr;   // nL + 1 -> pa/pb: products L[pa] L[pb]^T subtracted from this
   std::vector<int32_t> pa, pb;    //   block, in ascending REFERENCE position of the source column (direct.cpp)
   std::vector<int32_t> pcol;      //   ... and that source column k (the forward solve rides along)
+  std::vector<int32_t> tpre;      // blocks of the bottom groups that the top group's products read, ascending
+  std::vector<int32_t> tprey;     //   ... and the bottom columns whose y they read (the top group's warm-up)
   std::vector<int32_t> bord;      // nL: backward solve of column j visits its blocks bord[colptr[j] + 1 ...]
   std::vector<int32_t> brow;      //   ... whose rows are brow[same index] (a fixed order of summation that
                                   //   does not depend on the schedule; direct.cpp)

@@ -38,6 +38,9 @@ struct LdlArgs {
   const int32_t* lcolp;
   const int32_t* bord;
   const int32_t* brow;
+  const int32_t* tpre;   // the top group's warm-up lists (blocks of L, columns of y) and their lengths
+  const int32_t* tprey;
+  int32_t ntpre, ntprey;
   const int32_t* rptr;
   const int32_t* cells;
   const double* vals;  // block-CSR values of H (column-major 7x7)
@@ -195,6 +198,24 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
   const int lv0 = A.gptr[g], lv1 = A.gptr[g + 1];
   const bool trace = A.dbg != nullptr && UP && DOWN && threadIdx.x == 0;
   int ti = 0;
+  if (UP && DOWN && A.ntpre > 0) {
+    // The top group's operands from the bottom groups were written by other CUs of all XCDs: every
+    // dependent load of one would be a miss of this XCD's L2 (~2 us instead of ~0.7 per round trip,
+    // eight round trips per level).  Touch them all once, 16 per wavefront in flight, so that they are
+    // L2 hits when the product stream asks for them (round 3; nothing is kept in registers).
+    for (int t0 = wave * 16; t0 < A.ntpre; t0 += nw * 16) {
+      const int vt = t0 + (lane & 15) < A.ntpre ? A.tpre[t0 + (lane & 15)] : A.tpre[A.ntpre - 1];
+      double keep[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) keep[i] = A.L[(size_t)49 * __builtin_amdgcn_readlane(vt, i) + l49];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(keep[i]));
+    }
+    for (int t = threadIdx.x; t < A.ntprey * 7; t += blockDim.x) {
+      const double yk = A.y[(size_t)7 * A.tprey[t / 7] + t % 7];
+      asm volatile("" ::"v"(yk));
+    }
+  }
   if (UP) {
     for (int l = lv0; l < lv1; ++l) {
       const int q0 = A.rptr[l], q1 = A.rptr[l + 1];

@@ -917,6 +917,10 @@ class Engine {
     DCHK(direct_up(ldl.pcol, dplan.pcol, err));
     DCHK(direct_up(ldl.gptr, dplan.gptr, err));
     DCHK(direct_up(ldl.lcolp, dplan.lcolp, err));
+    DCHK(direct_up(ldl.tpre, dplan.tpre, err));
+    DCHK(direct_up(ldl.tprey, dplan.tprey, err));
+    ldl.ntpre = (int32_t)dplan.tpre.size();
+    ldl.ntprey = (int32_t)dplan.tprey.size();
     DCHK(direct_up(ldl.bord, dplan.bord, err));
     DCHK(direct_up(ldl.brow, dplan.brow, err));
     DCHK(direct_up(ldl.rptr, dplan.rptr, err));
