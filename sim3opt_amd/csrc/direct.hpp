@@ -56,6 +56,7 @@ struct DirectPlan {
   // everything it needs to issue its index loads.  Bottom groups run `sub_waves` wavefronts, the top
   // group CELL_WAVES.
   static constexpr int CELL_WAVES = 8, CELL_SLOTS = 8, CELL_STRIDE = 2 * (CELL_WAVES + 1);
+  static constexpr int STAGE_PRODUCTS = 112;  // products of one round (their operands are staged in LDS: 840 B each)
   int32_t sub_waves = 8;
   std::vector<int32_t> rptr;
   std::vector<int32_t> cells;

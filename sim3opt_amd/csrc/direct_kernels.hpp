@@ -10,16 +10,24 @@
 //   * once per linearisation k_ldl_gather sums every block's source blocks of H into `Aperm` and
 //     permutes b: a trial starts from there (+ lambda on the diagonal), without index chains;
 //   * the host split every level into rounds of cells (direct.hpp): ONE scalar read gives a
-//     wavefront its contiguous blocks and products; the product indices of a cell arrive by one
-//     vector load (lane = product), the operands of up to 8 products are requested together;
+//     wavefront its contiguous blocks and products, and every wavefront the product range of the round;
+//   * the operands of ALL the round's products (final blocks of earlier levels, y rows) are fetched by
+//     all wavefronts together into LDS -- one round trip for the indices, one for the blocks, four
+//     products per wavefront in flight (round 3; a round holds at most STAGE_PRODUCTS, a block with more
+//     is staged piece by piece);
 //   * phase A+B  per block in turn: raw = Aperm (+ lambda) - sum of the listed L(i,k) L(j,k)^T in
-//     list order; a diagonal block is factored right away (7x7 Cholesky and inverse through LDS,
-//     forward solve y_j riding along), an off-diagonal block waits in LDS;
+//     list order, entry (r, c) = row r of one staged block times row c of the other, read from LDS
+//     as broadcasts (no shuffles); a diagonal block is factored right away (7x7 Cholesky and inverse
+//     in registers, forward solve y_j riding along), an off-diagonal block waits in LDS;
 //   * barrier; phase C: off-diagonal blocks times L(j,j)^-T; barrier.
 // The backward solve walks the levels downwards, a wavefront per column.
 // Lane l of a wavefront holds entry l49 = l mod 49 of a column-major 7x7 block (lanes 49..63 mirror
-// lanes 0..14: every lane issues a valid load); 7x7x7 products go through the LDS crossbar
-// (ds_bpermute).  No atomics, fixed summation order: bit-reproducible.
+// lanes 0..14: every lane issues a valid load).  No atomics, fixed summation order that does not
+// depend on the schedule (direct.cpp): bit-reproducible.
+// Where the time of a level went (wall_clock64 stamps, KITTI-00, a level of one column with 16
+// products): round 2 -- 8 memory round trips for the products, two at a time, 6 us; 7x7 Cholesky by one
+// lane walking its LDS copy, 2.6 us; 10-12 us in all.  Now: staging 1.5, products from LDS 2.9, Cholesky
+// + inverse in registers + y 2.0, phase C 0.8 = 7.2 us.
 #pragma once
 // (included inside namespace sim3opt)
 
@@ -64,6 +72,7 @@ constexpr int LDL_WG_SUB = 512;                          // bottom subtrees: 8 w
 constexpr int LDL_CS = DirectPlan::CELL_SLOTS;
 constexpr int LDL_ST = DirectPlan::CELL_STRIDE;
 constexpr int LDL_NW = DirectPlan::CELL_WAVES;
+constexpr int LDL_STAGE = DirectPlan::STAGE_PRODUCTS;  // products whose operands one piece stages in LDS (92 KB)
 
 // sum over the 7 lanes that share this lane's column index c (lanes 7c .. 7c+6)
 __device__ __forceinline__ double ldl_sum_over_r(double v, int c49) {
@@ -102,39 +111,54 @@ __device__ __forceinline__ void ldl_factor_diag(const LdlArgs& A, int s, int j, 
   if (lane < 49) w[lane] = acc;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {  // lower triangle, entry (r, c) at r + 7c
-    bool ok = true;
+  // The 7x7 Cholesky and the triangular inverse run in REGISTERS (round 3): every lane reads the block from
+  // LDS once (28 broadcast reads) and works through the same operations in the same order as before, when
+  // lane 0 walked the LDS copy entry by entry -- ~200 dependent LDS round trips, 7 of a level's 10 us.
+  double a[7][7];  // lower triangle
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      double d = w[k + 7 * k];
+  for (int cc = 0; cc < 7; ++cc)
 #pragma unroll
-      for (int m = 0; m < k; ++m) d -= w[k + 7 * m] * w[k + 7 * m];
-      if (!(d > 0.0) || !(d < DBL_MAX)) { ok = false; d = 1.0; }  // not positive definite (g2o: the solve fails)
-      const double lkk = sqrt(d), inv = 1.0 / lkk;
-      w[k + 7 * k] = lkk;
+    for (int rr = cc; rr < 7; ++rr) a[rr][cc] = w[rr + 7 * cc];
+  bool ok = true;
 #pragma unroll
-      for (int rr = k + 1; rr < 7; ++rr) {
-        double v = w[rr + 7 * k];
+  for (int k = 0; k < 7; ++k) {
+    double d = a[k][k];
 #pragma unroll
-        for (int m = 0; m < k; ++m) v -= w[rr + 7 * m] * w[k + 7 * m];
-        w[rr + 7 * k] = v * inv;
-      }
+    for (int m = 0; m < k; ++m) d -= a[k][m] * a[k][m];
+    if (!(d > 0.0) || !(d < DBL_MAX)) { ok = false; d = 1.0; }  // not positive definite (g2o: the solve fails)
+    const double lkk = sqrt(d), inv = 1.0 / lkk;
+    a[k][k] = lkk;
 #pragma unroll
-      for (int rr = 0; rr < k; ++rr) w[rr + 7 * k] = 0.0;  // upper triangle
+    for (int rr = k + 1; rr < 7; ++rr) {
+      double v = a[rr][k];
+#pragma unroll
+      for (int m = 0; m < k; ++m) v -= a[rr][m] * a[k][m];
+      a[rr][k] = v * inv;
     }
-    if (!ok) A.sc->fail = 1;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 7) {  // column `lane` of the inverse of the lower-triangular factor
-    const int cc = lane;
+  if (!ok && lane == 0) A.sc->fail = 1;
+  // column `lane` of the inverse of the lower-triangular factor (lanes 0..6; the others follow along)
+  double wic[7];
+  {
+    const int cc = lane < 7 ? lane : 0;
 #pragma unroll
     for (int rr = 0; rr < 7; ++rr) {
       double v = rr == cc ? 1.0 : 0.0;
 #pragma unroll
-      for (int m = 0; m < rr; ++m) v -= w[rr + 7 * m] * (m >= cc ? wi[m + 7 * cc] : 0.0);
-      wi[rr + 7 * cc] = rr >= cc ? v / w[rr + 7 * rr] : 0.0;
+      for (int m = 0; m < rr; ++m) v -= a[rr][m] * (m >= cc ? wic[m] : 0.0);
+      wic[rr] = rr >= cc ? v / a[rr][rr] : 0.0;
     }
+  }
+  __builtin_amdgcn_wave_barrier();  // (everybody has read w)
+  if (lane == 0) {
+#pragma unroll
+    for (int cc = 0; cc < 7; ++cc)
+#pragma unroll
+      for (int rr = 0; rr < 7; ++rr) w[rr + 7 * cc] = rr >= cc ? a[rr][cc] : 0.0;
+  }
+  if (lane < 7) {
+#pragma unroll
+    for (int rr = 0; rr < 7; ++rr) wi[rr + 7 * lane] = wic[rr];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -189,6 +213,10 @@ template <bool UP, bool DOWN>
 __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
   __shared__ double lds_raw[LDL_NW][LDL_CS][49];  // a cell's blocks: Aperm rows, then raw blocks
   __shared__ double lds_ch[LDL_NW][98];           // Cholesky scratch
+  // the operands of a round's products (L(i,k), L(j,k), y_k), staged by all wavefronts together
+  __shared__ double st_a[UP ? LDL_STAGE : 1][49];
+  __shared__ double st_b[UP ? LDL_STAGE : 1][49];
+  __shared__ double st_y[UP ? LDL_STAGE : 1][7];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
@@ -223,7 +251,8 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
       for (int q = q0; q < q1; ++q) {
         const int32_t* cell = A.cells + (size_t)LDL_ST * q;
         const int sa = cell[wave], sb = cell[wave + 1];
-        const int ka = cell[LDL_NW + 1 + wave], kb = cell[LDL_NW + 1 + wave + 1];
+        const int ka = cell[LDL_NW + 1 + wave];
+        const int K0 = cell[LDL_NW + 1], K1 = cell[LDL_NW + 1 + LDL_NW];  // all products of the round
         const int n = sb - sa;  // <= LDL_CS
         // ---- index vectors of the cell and its Aperm rows: one round trip ----
         const int li_ = lane < n ? lane : (n > 0 ? n - 1 : 0);
@@ -233,9 +262,6 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
           vlc = A.lcol[sa + li_];
           vlr = A.lrow[sa + li_];
         }
-        int kbase = ka;
-        int ia = 0, ib = 0, ic = 0;
-        if (kbase + lane < kb) { ia = A.pa[kbase + lane]; ib = A.pb[kbase + lane]; ic = A.pcol[kbase + lane]; }
         {
           double tmp[LDL_CS];
 #pragma unroll
@@ -245,9 +271,13 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
           for (int t = 0; t < LDL_CS; ++t)
             if (t < n && lane < 49) lds_raw[wave][t][lane] = tmp[t];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase A + B: the cell's products as one stream, eight operands pairs at a time ----
+        // ---- phase A + B: the cell's products as one stream out of LDS ----
+        // A product's operands are final blocks of earlier levels.  Fetched by the wavefront that owns the
+        // target block they cost it a memory round trip per two products -- eight in a row where a level
+        // is one column with 16 products and seven wavefronts wait at the barrier (round 2).  Now every
+        // wavefront fetches its share of ALL the round's operands (four products in flight) into LDS and
+        // the owners run their chains of multiply-adds -- the same ones in the same order -- from there.
+        // The host keeps a round within LDL_STAGE products; a block with more is staged piece by piece.
         int t = 0, k = ka, kend = 0, jt = 0;
         bool diag = false;
         double acc = 0.0, tacc = 0.0, bpv = 0.0;
@@ -264,50 +294,64 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
           if (diag) ldl_factor_diag(A, sa + t, jt, acc, tacc, bpv, lane, l49, r, c, lds_ch[wave]);
           else if (lane < 49) lds_raw[wave][t][lane] = acc;  // waits for L(j,j)^-1 (phase C)
         };
-        if (n > 0) begin_slot();
-        while (t < n) {
-          if (k == kend) {  // this block has all its products
-            end_slot();
-            ++t;
-            if (t < n) begin_slot();
-            continue;
-          }
-          if (k - kbase >= 64) {  // next 64 product indices
-            kbase = k;
-            ia = ib = ic = 0;
-            if (kbase + lane < kb) { ia = A.pa[kbase + lane]; ib = A.pb[kbase + lane]; ic = A.pcol[kbase + lane]; }
-          }
-          const int off = k - kbase;
-          constexpr int PBATCH = 2;  // products in flight (3 and more spill: the kernel sits at 227 VGPRs)
-          int m = kb - k < PBATCH ? kb - k : PBATCH;
-          if (64 - off < m) m = 64 - off;
-          // L(i,k) arrives in the lane's own layout and is shuffled; row c of L(j,k) -- the other
-          // operand of entry (r, c) -- is read straight from memory (seven strided loads from lines
-          // that one load of the block would fetch anyway): half the LDS-crossbar traffic
-          double av[PBATCH], bm[PBATCH][7], yv[PBATCH];
+        bool started = false;
+        for (int c0 = K0;; c0 += LDL_STAGE) {
+          const int c1 = K1 - c0 < LDL_STAGE ? K1 : c0 + LDL_STAGE;
+          if (c1 > c0) {  // stage products [c0, c1): this wavefront's are c0 + wave, + nw, ...
+            const int pl = c0 + wave + nw * lane;
+            int ja = 0, jb = 0, jc = 0;
+            if (pl < c1) { ja = A.pa[pl]; jb = A.pb[pl]; jc = A.pcol[pl]; }
+            const int cnt = c1 - c0 > wave ? (c1 - c0 - wave + nw - 1) / nw : 0;
+            for (int i0 = 0; i0 < cnt; i0 += 4) {
+              double va[4], vb[4], vy[4];
 #pragma unroll
-          for (int i = 0; i < PBATCH; ++i)
-            if (i < m) {
-              const int s_a = __builtin_amdgcn_readlane(ia, off + i);
-              const int s_b = __builtin_amdgcn_readlane(ib, off + i);
-              av[i] = A.L[(size_t)49 * s_a + l49];
+              for (int i = 0; i < 4; ++i)
+                if (i0 + i < cnt) {
+                  va[i] = A.L[(size_t)49 * __builtin_amdgcn_readlane(ja, i0 + i) + l49];
+                  vb[i] = A.L[(size_t)49 * __builtin_amdgcn_readlane(jb, i0 + i) + l49];
+                  vy[i] = A.y[(size_t)7 * __builtin_amdgcn_readlane(jc, i0 + i) + r];
+                }
 #pragma unroll
-              for (int mm = 0; mm < 7; ++mm) bm[i][mm] = A.L[(size_t)49 * s_b + c + 7 * mm];
-              yv[i] = A.y[(size_t)7 * __builtin_amdgcn_readlane(ic, off + i) + c];
+              for (int i = 0; i < 4; ++i)
+                if (i0 + i < cnt) {
+                  const int slot = wave + nw * (i0 + i);
+                  if (lane < 49) { st_a[slot][lane] = va[i]; st_b[slot][lane] = vb[i]; }
+                  if (lane < 7) st_y[slot][lane] = vy[i];
+                }
             }
-#pragma unroll
-          for (int i = 0; i < PBATCH; ++i)
-            if (i < m) {
-              while (k + i == kend) {  // (a block boundary inside the batch)
-                end_slot();
-                ++t;
-                begin_slot();  // t < n: product k + i belongs to a block of this cell
-              }
-#pragma unroll
-              for (int mm = 0; mm < 7; ++mm) acc -= __shfl(av[i], 7 * mm + r) * bm[i][mm];
-              tacc += av[i] * yv[i];  // (used by diagonal blocks only)
+          }
+          __syncthreads();  // (also orders this wavefront's lds_raw rows before its own reads)
+          if (!started) {
+            started = true;
+            if (n > 0) begin_slot();
+          }
+          while (t < n) {
+            if (k == kend) {  // this block has all its products
+              end_slot();
+              ++t;
+              if (t < n) begin_slot();
+              continue;
             }
-          k += m;
+            if (k >= c1) break;  // the rest of this block's products are in the next piece
+            // entry (r, c) of L(i,k) L(j,k)^T: row r of the one staged block times row c of the other, read
+            // straight from LDS (seven lanes share an address: broadcasts) -- no shuffles; one product at a
+            // time (requesting product k + 1 before the multiply-adds of k costs more in register copies than
+            // the LDS round trip it hides: measured)
+            const int sl = k - c0;
+            double am[7], bm[7];
+#pragma unroll
+            for (int mm = 0; mm < 7; ++mm) {
+              am[mm] = st_a[sl][r + 7 * mm];
+              bm[mm] = st_b[sl][c + 7 * mm];
+            }
+            const double av = st_a[sl][l49], yv = st_y[sl][c];
+#pragma unroll
+            for (int mm = 0; mm < 7; ++mm) acc -= am[mm] * bm[mm];
+            tacc += av * yv;  // (used by diagonal blocks only)
+            ++k;
+          }
+          if (c1 >= K1) break;
+          __syncthreads();  // everybody is done with this piece before the next one overwrites it
         }
         __syncthreads();
         if (trace && ti < 254) A.dbg[ti++] = wall_clock64();
