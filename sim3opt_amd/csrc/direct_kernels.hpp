@@ -334,10 +334,33 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
             }
             if (k >= c1) break;  // the rest of this block's products are in the next piece
             // entry (r, c) of L(i,k) L(j,k)^T: row r of the one staged block times row c of the other, read
-            // straight from LDS (seven lanes share an address: broadcasts) -- no shuffles; one product at a
-            // time (requesting product k + 1 before the multiply-adds of k costs more in register copies than
-            // the LDS round trip it hides: measured)
+            // straight from LDS (seven lanes share an address: broadcasts) -- no shuffles; two products of a
+            // block at a time where it has two left (a rotating prefetch of product k + 1 cost more in
+            // register copies than the LDS round trip it hid: measured)
             const int sl = k - c0;
+            if (k + 1 < kend && k + 1 < c1) {  // two products of this block: their reads in flight together
+              double am[7], bm[7], am2[7], bm2[7];
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) {
+                am[mm] = st_a[sl][r + 7 * mm];
+                bm[mm] = st_b[sl][c + 7 * mm];
+              }
+              const double av = st_a[sl][l49], yv = st_y[sl][c];
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) {
+                am2[mm] = st_a[sl + 1][r + 7 * mm];
+                bm2[mm] = st_b[sl + 1][c + 7 * mm];
+              }
+              const double av2 = st_a[sl + 1][l49], yv2 = st_y[sl + 1][c];
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) acc -= am[mm] * bm[mm];
+              tacc += av * yv;
+#pragma unroll
+              for (int mm = 0; mm < 7; ++mm) acc -= am2[mm] * bm2[mm];
+              tacc += av2 * yv2;
+              k += 2;
+              continue;
+            }
             double am[7], bm[7];
 #pragma unroll
             for (int mm = 0; mm < 7; ++mm) {
