@@ -1,6 +1,7 @@
 // devmem.cpp -- see devmem.hpp
 #include "devmem.hpp"
 
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -15,6 +16,11 @@ constexpr size_t MAX_TOTAL = (size_t)1 << 30;
 
 struct Cache {
   std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> streams;                 // idle, per device
+  std::map<int, std::vector<hipEvent_t>> events;
+  std::map<std::pair<int, size_t>, std::vector<void*>> host_free;  // pinned blocks
+  std::unordered_map<void*, std::pair<int, size_t>> host_live;
+  size_t host_cached = 0;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;  // (device, rounded size) -> blocks
   std::unordered_map<void*, std::pair<int, size_t>> live;            // blocks handed out by dev_malloc
   size_t cached_bytes = 0;
@@ -38,6 +44,16 @@ void release_locked(Cache& c) {
     for (void* p : kv.second) (void)hipFree(p);
   c.free_blocks.clear();
   c.cached_bytes = 0;
+  for (auto& kv : c.streams)
+    for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+  c.streams.clear();
+  for (auto& kv : c.events)
+    for (hipEvent_t e : kv.second) (void)hipEventDestroy(e);
+  c.events.clear();
+  for (auto& kv : c.host_free)
+    for (void* p : kv.second) (void)hipHostFree(p);
+  c.host_free.clear();
+  c.host_cached = 0;
 }
 
 }  // namespace
@@ -93,6 +109,128 @@ int handle_count(int delta) {
   std::lock_guard<std::mutex> lock(mu);
   n += delta;
   return n;
+}
+
+hipError_t stream_acquire(hipStream_t* s) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Cache& c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    std::vector<hipStream_t>& v = c.streams[dev];
+    if (!v.empty()) {
+      *s = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+void stream_release(hipStream_t s) {
+  if (!s) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Cache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  std::vector<hipStream_t>& v = c.streams[dev];
+  if (v.size() < 8) v.push_back(s);
+  else (void)hipStreamDestroy(s);
+}
+
+hipError_t event_acquire(hipEvent_t* e) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Cache& c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    std::vector<hipEvent_t>& v = c.events[dev];
+    if (!v.empty()) {
+      *e = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipEventCreate(e);
+}
+
+void event_release(hipEvent_t e) {
+  if (!e) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Cache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  std::vector<hipEvent_t>& v = c.events[dev];
+  if (v.size() < 4096) v.push_back(e);
+  else (void)hipEventDestroy(e);
+}
+
+hipError_t host_malloc(void** p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t sz = rounded(bytes);
+  Cache& c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.host_free.find({dev, sz});
+    if (it != c.host_free.end() && !it->second.empty()) {
+      *p = it->second.back();
+      it->second.pop_back();
+      c.host_cached -= sz;
+      c.host_live[*p] = {dev, sz};
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = hipHostMalloc(p, sz);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.host_live[*p] = {dev, sz};
+  }
+  return e;
+}
+
+void host_free(void* p) {
+  if (!p) return;
+  Cache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  auto it = c.host_live.find(p);
+  if (it == c.host_live.end()) {
+    (void)hipHostFree(p);
+    return;
+  }
+  const std::pair<int, size_t> key = it->second;
+  c.host_live.erase(it);
+  if (key.second <= ((size_t)8 << 20) && c.host_cached + key.second <= ((size_t)64 << 20)) {
+    c.host_free[key].push_back(p);
+    c.host_cached += key.second;
+  } else {
+    (void)hipHostFree(p);
+  }
+}
+
+hipError_t StagedUploads::put(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes <= MAX_ITEM) {
+    if (!base_) {
+      void* p = nullptr;
+      if (host_malloc(&p, BLOCK) == hipSuccess) base_ = static_cast<char*>(p);
+      else (void)hipGetLastError();
+      off_ = 0;
+    }
+    if (base_ && off_ + bytes <= BLOCK) {
+      std::memcpy(base_ + off_, src, bytes);
+      const hipError_t e = hipMemcpyAsync(dst, base_ + off_, bytes, hipMemcpyHostToDevice, stream);
+      off_ = (off_ + bytes + 63) & ~(size_t)63;
+      return e;
+    }
+  }
+  return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+void StagedUploads::release() {
+  if (base_) host_free(base_);
+  base_ = nullptr;
+  off_ = 0;
 }
 
 void dev_cache_release() {

@@ -94,11 +94,12 @@ struct DevScalars {
 // Engine
 // ------------------------------------------------------------------------------------------
 template <typename T>
-static hipError_t upload(T*& dptr, const std::vector<T>& h) {
+static hipError_t upload(StagedUploads& staged, hipStream_t stream, T*& dptr, const std::vector<T>& h) {
   const size_t bytes = sizeof(T) * std::max<size_t>(h.size(), 1);
   hipError_t e = dev_malloc((void**)&dptr, bytes);
   if (e != hipSuccess) return e;
-  if (!h.empty()) e = hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice);
+  // (small arrays: staged in pinned memory and enqueued; init synchronises once at its end)
+  if (!h.empty()) e = staged.put(dptr, h.data(), sizeof(T) * h.size(), stream);
   return e;
 }
 
@@ -191,6 +192,7 @@ class Engine {
   int graph_iters = PCG_GRAPH_ITERS;
   DevScalars* d_sc = nullptr;
   DevScalars* h_sc = nullptr;  // pinned
+  StagedUploads staged;        // small uploads of init() go through one pinned block, on `stream`
   bool linearized = false;
   // multi-GPU row partition: this rank owns block rows [r0, r1); offs = 7 * row_begin
   Comm comm;
@@ -231,13 +233,14 @@ class Engine {
     for (void* p : direct_owned)
       if (p) dev_free(p);
     direct_owned.clear();
-    if (h_sc) (void)hipHostFree(h_sc);
-    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
-    if (ev_a) (void)hipEventDestroy(ev_a);
-    if (ev_b) (void)hipEventDestroy(ev_b);
-    for (hipEvent_t& e : ev_ph) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    staged.release();
+    if (h_sc) host_free(h_sc);
+    for (hipEvent_t e : pool) event_release(e);
+    if (ev_a) event_release(ev_a);
+    if (ev_b) event_release(ev_b);
+    for (hipEvent_t& e : ev_ph) if (e) { event_release(e); e = nullptr; }
     if (pcg_graph) (void)hipGraphExecDestroy(pcg_graph);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) stream_release(stream);  // (synchronised above; kept for the next engine on this device)
     comm.release();
   }
 
@@ -265,6 +268,7 @@ class Engine {
       int a = 0, b = 0;
       if (std::sscanf(ev, "%d,%d", &a, &b) == 2) { spmv_chunk = a; spmv_nt = b; }
     }
+    HIPCHK(stream_acquire(&stream));
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
     // row partition (world == 1: everything is local)
@@ -292,7 +296,7 @@ class Engine {
         for (int r = 0; r < comm.world; ++r)
           std::copy(brow_list.begin() + halo_seg[r], brow_list.begin() + halo_seg[r + 1],
                     padded.begin() + (size_t)halo_slots * r);
-        HIPCHK(upload(d_brow, padded));
+        HIPCHK(upload(staged, stream, d_brow, padded));
         HIPCHK(dev_malloc((void**)&d_halo, sizeof(double) * 7 * padded.size()));
         HIPCHK(hipMemset(d_halo, 0, sizeof(double) * 7 * padded.size()));
       }
@@ -322,22 +326,21 @@ class Engine {
     const bool itrace = std::getenv("SIM3OPT_INIT_TRACE") != nullptr;
     auto inow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double it0 = inow();
-    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&ev_a));
-    HIPCHK(hipEventCreate(&ev_b));
-    for (hipEvent_t& e : ev_ph) HIPCHK(hipEventCreate(&e));
-    HIPCHK(upload(d_states, g.states));
+    HIPCHK(event_acquire(&ev_a));
+    HIPCHK(event_acquire(&ev_b));
+    for (hipEvent_t& e : ev_ph) HIPCHK(event_acquire(&e));
+    HIPCHK(upload(staged, stream, d_states, g.states));
     HIPCHK(dev_malloc((void**)&d_backup, sizeof(Sim3) * (size_t)nv));
-    HIPCHK(upload(d_meas, g.meas));
-    HIPCHK(upload(d_ev0, g.ev0));
-    HIPCHK(upload(d_ev1, g.ev1));
-    HIPCHK(upload(d_hidx, s.hidx));
-    HIPCHK(upload(d_active, l_active));
-    if (has_info) HIPCHK(upload(d_info, g.info));
-    if (has_kernel) HIPCHK(upload(d_kdelta, g.kdelta));
-    HIPCHK(upload(d_rowptr, s.rowptr));
-    HIPCHK(upload(d_colidx, s.colidx));
-    HIPCHK(upload(d_incptr, s.incptr));
+    HIPCHK(upload(staged, stream, d_meas, g.meas));
+    HIPCHK(upload(staged, stream, d_ev0, g.ev0));
+    HIPCHK(upload(staged, stream, d_ev1, g.ev1));
+    HIPCHK(upload(staged, stream, d_hidx, s.hidx));
+    HIPCHK(upload(staged, stream, d_active, l_active));
+    if (has_info) HIPCHK(upload(staged, stream, d_info, g.info));
+    if (has_kernel) HIPCHK(upload(staged, stream, d_kdelta, g.kdelta));
+    HIPCHK(upload(staged, stream, d_rowptr, s.rowptr));
+    HIPCHK(upload(staged, stream, d_colidx, s.colidx));
+    HIPCHK(upload(staged, stream, d_incptr, s.incptr));
     {  // span SpMV: contiguous row span per wavefront, balanced by stored blocks
       const int nloc = r1 - r0;
       // 3x the resident set (256 CUs x 8 workgroups of 4 wavefronts): shorter spans make the
@@ -353,12 +356,12 @@ class Engine {
       std::vector<int32_t> wrow(nw + 1);
       partition_rows(nloc, s.rowptr.data() + r0, nw, wrow.data());
       for (int32_t& w : wrow) w += r0;
-      HIPCHK(upload(d_wrow, wrow));
+      HIPCHK(upload(staged, stream, d_wrow, wrow));
     }
-    HIPCHK(upload(d_slot01, l_s01));
-    HIPCHK(upload(d_slot10, l_s10));
-    HIPCHK(upload(d_inc0, l_i0));
-    HIPCHK(upload(d_inc1, l_i1));
+    HIPCHK(upload(staged, stream, d_slot01, l_s01));
+    HIPCHK(upload(staged, stream, d_slot10, l_s10));
+    HIPCHK(upload(staged, stream, d_inc0, l_i0));
+    HIPCHK(upload(staged, stream, d_inc1, l_i1));
     HIPCHK(dev_malloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
     HIPCHK(hipMemset(d_vals, 0, sizeof(double) * 49 * (size_t)nnzb));
     const size_t ninc = (size_t)s.incptr[nb];
@@ -408,8 +411,8 @@ class Engine {
             if (sf[i] < 0) sf[i] = k;
             ++scnt[i];
           }
-      HIPCHK(upload(d_sub_first, sf));
-      HIPCHK(upload(d_sub_cnt, scnt));
+      HIPCHK(upload(staged, stream, d_sub_first, sf));
+      HIPCHK(upload(staged, stream, d_sub_cnt, scnt));
       HIPCHK(dev_malloc((void**)&d_Gm, sizeof(double) * 49 * (size_t)nb));
     }
     double** vecs[] = {&d_b, &d_x, &d_r, &d_z, &d_p, &d_q, &d_s};
@@ -429,7 +432,7 @@ class Engine {
     HIPCHK(dev_malloc((void**)&d_part_b, sizeof(double) * SPAN_GRID_MAX));
     HIPCHK(dev_malloc((void**)&d_sc, sizeof(DevScalars)));
     HIPCHK(hipMemset(d_sc, 0, sizeof(DevScalars)));
-    HIPCHK(hipHostMalloc((void**)&h_sc, sizeof(DevScalars)));
+    HIPCHK(host_malloc((void**)&h_sc, sizeof(DevScalars)));
     // Gram task tables
     GramTables tab;
     int t = 0;
@@ -440,6 +443,7 @@ class Engine {
       for (int r = 0; r <= c; ++r) { tab.tr[t] = (unsigned char)r; tab.tc[t] = (unsigned char)c; ++t; }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tab, sizeof(tab)));
     HIPCHK(hipDeviceSynchronize());
+    staged.release();
     if (itrace)
       std::fprintf(stderr, "sim3opt engine init: uploads %.2f ms, factorisation plan + its uploads %.2f ms, rest %.2f ms\n",
                    it1 - it0, it2 - it1, inow() - it2);
@@ -469,8 +473,8 @@ class Engine {
   int pool_get(hipEvent_t& a, hipEvent_t& b, std::string& err) {
     if (pool_used + 2 > pool.size()) {
       hipEvent_t e0, e1;
-      HIPCHK(hipEventCreate(&e0));
-      HIPCHK(hipEventCreate(&e1));
+      HIPCHK(event_acquire(&e0));
+      HIPCHK(event_acquire(&e1));
       pool.push_back(e0);
       pool.push_back(e1);
     }
@@ -504,7 +508,7 @@ class Engine {
   int amg_up(T*& dptr, const std::vector<T>& h, std::string& err) {
     HIPCHK(dev_malloc((void**)&dptr, sizeof(T) * std::max<size_t>(h.size(), 1)));
     amg_owned.push_back(dptr);
-    if (!h.empty()) HIPCHK(hipMemcpy(dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    if (!h.empty()) HIPCHK(staged.put(dptr, h.data(), sizeof(T) * h.size(), stream));
     return SIM3OPT_OK;
   }
   int amg_alloc(double*& dptr, size_t count, std::string& err) {
@@ -863,7 +867,7 @@ class Engine {
     T* p = nullptr;
     HIPCHK(dev_malloc((void**)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
     direct_owned.push_back(p);
-    if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    if (!h.empty()) HIPCHK(staged.put(p, h.data(), sizeof(T) * h.size(), stream));
     dptr = p;
     return SIM3OPT_OK;
   }
