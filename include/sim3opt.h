@@ -284,7 +284,8 @@ int sim3opt_partition_plan(sim3opt_graph* g, int32_t world, int32_t locality, in
 int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end);
 
 /* Returns the device blocks the library keeps for re-use (graphs that are re-initialised after growing
- * by an edge find their predecessor's buffers, csrc/devmem.cpp; at most 1 GB) to the HIP runtime.
+ * by an edge find their predecessor's buffers, csrc/devmem.cpp; at most 1 GB) to the HIP runtime, together
+ * with the idle streams, events and pinned host blocks (<= 64 MB) it recycles the same way.
  * Called automatically when the last sim3opt_graph / sim3opt_ba handle of the process is destroyed;
  * call it yourself before allocating large device buffers of your own next to a live handle. */
 void sim3opt_release_device_cache(void);
