@@ -61,6 +61,7 @@ struct LdlArgs {
   double* xp;          // 7 nb, elimination order
   double* x;           // 7 nb, block rows of H (the result)
   int32_t nb, nL;
+  int32_t fail_token = 1;  // what a non-positive pivot writes into sc->fail (the engine: a number per solve)
   double lambda;
   DevScalars* sc;
   long long* dbg;  // tuning aid (SIM3OPT_DIRECT_TRACE): wall_clock64 stamps of the top group's levels
@@ -136,7 +137,7 @@ __device__ __forceinline__ void ldl_factor_diag(const LdlArgs& A, int s, int j, 
       a[rr][k] = v * inv;
     }
   }
-  if (!ok && lane == 0) A.sc->fail = 1;
+  if (!ok && lane == 0) A.sc->fail = A.fail_token;
   // column `lane` of the inverse of the lower-triangular factor (lanes 0..6; the others follow along)
   double wic[7];
   {

@@ -181,6 +181,7 @@ class Engine {
   bool use_direct = false;
   LdlArgs ldl{};
   int ldl_wg_sub = LDL_WG_SUB;
+  int fail_token = 1;  // number of the current exact solve (>= 2): see direct_solve
   std::vector<void*> direct_owned;
   // chi2 of the current estimates when it is already known (the last accepted trial computed it)
   bool chi_known = false;
@@ -957,7 +958,9 @@ class Engine {
   // (H + lambda I) x = b, exactly; x in d_x.  A non-positive pivot raises d_sc->fail (read by the
   // caller together with the trial's chi2: no extra round trip).
   int direct_solve(double lambda, std::string& err) {
-    hipLaunchKernelGGL(k_reset_fail, dim3(1), dim3(1), 0, stream, d_sc);
+    // (no reset of d_sc->fail: a failing factorisation stores this solve's token there, older values differ)
+    fail_token = fail_token >= (1 << 30) ? 2 : fail_token + 1;
+    ldl.fail_token = fail_token;
     ldl.vals = d_vals;
     ldl.b = d_b;
     ldl.x = d_x;
@@ -996,10 +999,16 @@ class Engine {
   }
 
   // ---- building blocks ----
-  int chi2(double* out, std::string& err, hipEvent_t before_fetch = nullptr) {
+  // scale_parts > 0: d_part_b holds that many partial sums of the trial's scale (k_scale): summed in the
+  // same launch as chi2's
+  int chi2(double* out, std::string& err, hipEvent_t before_fetch = nullptr, int scale_parts = 0) {
     const int g = grid_for(e_hi - e_lo, WG);
     hipLaunchKernelGGL(k_chi2, dim3(g), dim3(WG), 0, stream, edge_args(), d_part_a);
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
+    if (scale_parts > 0)
+      hipLaunchKernelGGL(k_final_sum_two, dim3(1), dim3(WG), 0, stream, (const double*)d_part_a, g, &d_sc->chi2,
+                         (const double*)d_part_b, scale_parts, &d_sc->scale);
+    else
+      hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
     HIPCHK(hipGetLastError());
     int rc = SIM3OPT_OK;
     if (comm.active()) {  // chi2 and scale are adjacent: one 2-double all-reduce per LM trial
@@ -1473,20 +1482,19 @@ class Engine {
         double scale = 0.0;
         if (ok2) {
           hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
-                             d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr, d_backup);
+                             d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr, d_backup,
+                             fail_token);
           const int ge = grid_for(7 * (int64_t)(r1 - r0), WG);
           hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
                              lambda, d_part_b);
-          hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_b, ge,
-                             &d_sc->scale);
           HIPCHK(hipGetLastError());
-          rc = chi2(&tempChi, err, ev_ph[3]);  // also brings back scale (and the factorisation's verdict)
+          rc = chi2(&tempChi, err, ev_ph[3], ge);  // also sums and brings back scale (and the factorisation's verdict)
           if (rc) return rc;
           rc = elapsed(2, 3, T.ms_update);
           if (rc) return rc;
           scale = h_sc->scale;
           kt.n_update += 1;
-          if (use_direct && h_sc->fail) {  // not positive definite: g2o's solver returns false
+          if (use_direct && h_sc->fail == fail_token) {  // not positive definite: g2o's solver returns false
             tempChi = DBL_MAX;
             scale = 0.0;
           }
@@ -1654,7 +1662,7 @@ int engine_solve(Engine* e, double lambda, double* x, int32_t* iters, double* re
   if (e->use_direct) {  // the factorisation reports a non-positive pivot through the scalars
     rc = e->fetch_scalars(err);
     if (rc) return rc;
-    ok = !e->h_sc->fail;
+    ok = e->h_sc->fail != e->fail_token;
   }
   if (iters) *iters = it;
   if (rel_res) *rel_res = rr;

@@ -55,6 +55,21 @@ __global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa
   }
 }
 
+// chi2 and the step's scale delta^T (lambda delta + b) of an LM trial: two partial arrays of different lengths,
+// each summed exactly as k_final_sum sums it, in one launch (outa and outb are adjacent in DevScalars)
+__global__ __launch_bounds__(WG) void k_final_sum_two(const double* __restrict__ pa, int na,
+                                                      double* __restrict__ outa,
+                                                      const double* __restrict__ pb, int nb_,
+                                                      double* __restrict__ outb) {
+  __shared__ double sh[4];
+  const double a = sum_partials(pa, na, sh);
+  const double b = sum_partials(pb, nb_, sh);
+  if (threadIdx.x == 0) {
+    *outa = a;
+    *outb = b;
+  }
+}
+
 // multi-GPU: the breakdown flag is rank-local (a non-SPD block on one rank's rows); the ranks agree
 // on it through a max all-reduce of tmp_pq so that they keep taking the same branches
 __global__ void k_fail_to_double(DevScalars* sc) { sc->tmp_pq = sc->fail ? 1.0 : 0.0; }

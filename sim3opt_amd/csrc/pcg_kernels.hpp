@@ -521,11 +521,13 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
 // ------------------------------------------------------------------------------------------
 // VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
 // (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
-// fact; the step is then garbage and must not be applied -- the host rejects the trial)
+// fact -- it stores the solve's token there, so that nobody has to reset the flag between solves --;
+// the step is then garbage and must not be applied -- the host rejects the trial)
 // `backup` (may be null) receives the estimates as they were: g2o's push() without a copy of its own.
 __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
                                               const double* __restrict__ x, Sim3* states,
-                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup) {
+                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup,
+                                              int fail_token) {
   const int v = blockIdx.x * WG + threadIdx.x;
   if (v >= nv) return;
   if (backup) {
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) b8[i] = s8[i];
   }
-  if (sc && sc->fail) return;
+  if (sc && sc->fail == fail_token) return;
   const int h = hidx[v];
   if (h < 0) return;
   double xi[7];
@@ -553,7 +555,6 @@ __global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restri
   if (i < 8 * nv) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
 }
 
-__global__ void k_reset_fail(DevScalars* sc) { sc->fail = 0; }
 
 // Halo exchange of the row-partitioned PCG (round 3): the boundary rows of a vector (rows with a
 // neighbour on another rank, host list `brow`, grouped by owner) are packed into one buffer, that
