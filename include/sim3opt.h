@@ -99,7 +99,9 @@ typedef struct sim3opt_iter_stats {
   int32_t trials;       /* LM trials used                      */
   int32_t pcg_iters;    /* PCG iterations summed over trials   */
   double pcg_rel_res;   /* last achieved relative residual     */
-  double ms_linearize;  /* device time, HIP events             */
+  double ms_linearize;  /* device time, HIP events; measured when options.time_kernels or .verbose is set
+                         * or the system has more than 4096 block rows, 0 otherwise (the three event
+                         * markers per trial are 7 % of a KITTI-00 iteration) */
   double ms_solve;
   double ms_update;     /* oplus + chi2 + scale                */
 } sim3opt_iter_stats;

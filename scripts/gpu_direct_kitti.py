@@ -14,7 +14,7 @@ def dense_from_system(G):
 out = {}
 for name, one in (("one_loop", True), ("all_118_loops", False)):
     g = K.build_direct_graph(one)
-    G = L.Graph(verbose=int(os.environ.get("VERBOSE", "0")))
+    G = L.Graph(verbose=int(os.environ.get("VERBOSE", "0")), time_kernels=1)  # (time_kernels: per-phase times on a small graph)
     G.add_vertices(g["states"], g["fixed"]); G.add_edges(g["v0"], g["v1"], g["meas"]); G.initialize()
     print(name, "linear solver in use:", G.linear_solver_in_use(), flush=True)
     G.linearize()

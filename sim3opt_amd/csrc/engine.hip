@@ -213,6 +213,10 @@ class Engine {
   // phase stamps of the LM loop (linearise | solve | update): recorded without waiting, read after
   // the trial's one host round trip (the chi2 fetch)
   hipEvent_t ev_ph[4] = {nullptr, nullptr, nullptr, nullptr};
+  // per-iteration phase times (IterStats::ms_*): three event markers per LM trial, ~5.6 us of idle stream each --
+  // nothing next to a 25 ms iteration, 7 % of a KITTI-00 one: measured on request (time_kernels, verbose) and
+  // on systems of more than 4096 block rows, reported as 0 otherwise
+  bool phase_timing = true;
   std::vector<hipEvent_t> pool;  // pairs (start, stop) for per-launch SpMV timing
   size_t pool_used = 0;
   sim3opt_kernel_times kt{};
@@ -270,6 +274,7 @@ class Engine {
       if (std::sscanf(ev, "%d,%d", &a, &b) == 2) { spmv_chunk = a; spmv_nt = b; }
     }
     HIPCHK(stream_acquire(&stream));
+    phase_timing = opt.time_kernels != 0 || opt.verbose != 0 || s.nb > 4096;
     st = s;
     nv = g.nv(); ne = g.ne(); nb = s.nb; n = 7 * nb; nnzb = s.nnzb;
     // row partition (world == 1: everything is local)
@@ -1437,7 +1442,7 @@ class Engine {
       // phase times: event stamps on the stream, read after the trial's chi2 fetch -- the loop has
       // ONE host round trip per trial (plus lambda_0's at the first iteration); waiting on every
       // phase's end event left the GPU idle a quarter of the time on the small graphs
-      HIPCHK(hipEventRecord(ev_ph[0], stream));
+      if (phase_timing) HIPCHK(hipEventRecord(ev_ph[0], stream));
       // computeActiveErrors at the start of an iteration: the estimates are those the last trial
       // evaluated (accepted) or restored (rejected), and the evaluation is deterministic, so the
       // value is already here -- one host round trip less per iteration
@@ -1462,19 +1467,20 @@ class Engine {
       double rho = 0.0;
       int qmax = 0;
       auto elapsed = [&](int a, int b, double& acc) -> int {
+        if (!phase_timing) return SIM3OPT_OK;
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev_ph[a], ev_ph[b]));
         acc += ms;
         return SIM3OPT_OK;
       };
       do {
-        HIPCHK(hipEventRecord(ev_ph[1], stream));  // (push(): k_oplus keeps the old estimates itself)
+        if (phase_timing) HIPCHK(hipEventRecord(ev_ph[1], stream));  // (push(): k_oplus keeps the old estimates itself)
         int32_t pit = 0;
         double rres = 0.0;
         bool ok2 = true;
         rc = pcg(lambda, &pit, &rres, &ok2, err);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(ev_ph[2], stream));
+        if (phase_timing) HIPCHK(hipEventRecord(ev_ph[2], stream));
         T.pcg_iters += pit;
         T.pcg_rel_res = rres;
         if (opt.verbose >= 2)
@@ -1488,7 +1494,7 @@ class Engine {
           hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
                              lambda, d_part_b);
           HIPCHK(hipGetLastError());
-          rc = chi2(&tempChi, err, ev_ph[3], ge);  // also sums and brings back scale (and the factorisation's verdict)
+          rc = chi2(&tempChi, err, phase_timing ? ev_ph[3] : nullptr, ge);  // also sums and brings back scale (and the factorisation's verdict)
           if (rc) return rc;
           rc = elapsed(2, 3, T.ms_update);
           if (rc) return rc;
@@ -1500,7 +1506,8 @@ class Engine {
           }
         } else {
           tempChi = DBL_MAX;  // solver failed: g2o forces rejection
-          HIPCHK(hipEventSynchronize(ev_ph[2]));
+          if (phase_timing) HIPCHK(hipEventSynchronize(ev_ph[2]));
+          else HIPCHK(hipStreamSynchronize(stream));
         }
         rc = elapsed(1, 2, T.ms_solve);
         if (rc) return rc;
