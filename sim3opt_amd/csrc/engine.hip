@@ -1059,8 +1059,9 @@ class Engine {
     }
     const int gdr = grid_for(r1 - r0, 4);
     hipLaunchKernelGGL(k_diag_reduce, dim3(gdr), dim3(WG), 0, stream, r0, r1,
-                       d_incptr, d_rowptr, d_scratch, d_vals, d_b, d_sc, d_part_a);
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, gdr, &d_sc->trace);
+                       d_incptr, d_rowptr, d_scratch, d_vals, d_b, d_sc, d_part_a, d_part_b);
+    hipLaunchKernelGGL(k_final_trace_max, dim3(1), dim3(WG), 0, stream, (const double*)d_part_a,
+                       (const double*)d_part_b, gdr, &d_sc->trace, &d_sc->maxdiag_bits);
     HIPCHK(hipGetLastError());
     if (comm.active()) {  // non-negative doubles order like their bit patterns
       int rc = comm.allreduce(reinterpret_cast<double*>(&d_sc->maxdiag_bits), 1, 1, stream, err);

@@ -42,6 +42,27 @@ __global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ par
   if (threadIdx.x == 0) *out = s;
 }
 
+// after k_diag_reduce: trace(H) (summed as k_final_sum sums it) and max |H_dd| over the workgroups' maxima
+__global__ __launch_bounds__(WG) void k_final_trace_max(const double* __restrict__ trace_partials,
+                                                        const double* __restrict__ max_partials, int n,
+                                                        double* __restrict__ trace_out,
+                                                        unsigned long long* __restrict__ maxdiag_bits) {
+  __shared__ double sh[4];
+  __shared__ double shm[4];
+  const double s = sum_partials(trace_partials, n, sh);
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += WG) m = fmax(m, max_partials[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *trace_out = s;
+    m = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+    *maxdiag_bits = (unsigned long long)__double_as_longlong(m);  // non-negative doubles order like their bits
+  }
+}
+
 // two sums in one launch (multi-GPU PCG: [w.z, r.z] land in adjacent doubles for one all-reduce)
 __global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa,
                                                    const double* __restrict__ pb, int n,
@@ -334,8 +355,10 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
                                                     const double* __restrict__ scratch,
                                                     double* __restrict__ vals,
                                                     double* __restrict__ b, DevScalars* sc,
-                                                    double* __restrict__ trace_partials) {
+                                                    double* __restrict__ trace_partials,
+                                                    double* __restrict__ max_partials) {
   __shared__ double sh[4];
+  __shared__ double shm[4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane % 7, c = lane / 7;
@@ -361,10 +384,15 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
-  if (lane == 0 && dmax > 0.0)
-    atomicMax(&sc->maxdiag_bits, (unsigned long long)__double_as_longlong(dmax));
-  const double ts = block_sum(tr, sh);  // fixed order: deterministic
-  if (threadIdx.x == 0) trace_partials[blockIdx.x] = ts;
+  // (one atomicMax per wavefront on sc->maxdiag_bits -- 8192 of them on one address -- was 80 of this kernel's
+  // 98 us on a 10k-vertex graph and a third of its 273 us on config 3: per-workgroup maxima now, reduced by
+  // k_final_trace_max together with the trace)
+  if (lane == 0) shm[wave] = dmax;
+  const double ts = block_sum(tr, sh);  // fixed order: deterministic (its barriers also publish shm)
+  if (threadIdx.x == 0) {
+    trace_partials[blockIdx.x] = ts;
+    max_partials[blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
