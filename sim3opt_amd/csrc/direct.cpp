@@ -406,26 +406,16 @@ bool build_direct_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
         }
         if (bounds.back() != S1) bounds.push_back(S1);
         const size_t ncell = bounds.size() - 1;
-        // rounds: up to nw cells in order, and no more products than the kernel stages in LDS at a time
-        // (a single cell with more is staged piece by piece)
-        for (size_t c = 0; c < ncell || c == 0;) {
-          size_t m = 0;
-          int64_t prod = 0;
-          while (c + m < ncell && (int)m < nw) {
-            const int64_t pc = P.pairptr[bounds[c + m + 1]] - P.pairptr[bounds[c + m]];
-            if (m > 0 && prod + pc > DirectPlan::STAGE_PRODUCTS) break;
-            prod += pc;
-            ++m;
-          }
+        const size_t R = std::max<size_t>(1, (ncell + nw - 1) / nw);
+        for (size_t q = 0; q < R; ++q) {
           const size_t base = P.cells.size();
           P.cells.resize(base + ST, S1);
           for (int w = 0; w <= NW; ++w) {
-            const size_t ci = c + std::min<size_t>((size_t)w, m);
-            const int32_t sb = ci < bounds.size() ? bounds[ci] : S1;
+            const size_t c = q * nw + (size_t)std::min(w, nw);
+            const int32_t sb = c < bounds.size() ? bounds[c] : S1;
             P.cells[base + w] = sb;
             P.cells[base + NW + 1 + w] = P.pairptr[sb];
           }
-          c += std::max<size_t>(m, 1);
         }
         P.rptr.push_back((int32_t)(P.cells.size() / ST));
       }

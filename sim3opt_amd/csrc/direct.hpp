@@ -56,7 +56,8 @@ struct DirectPlan {
   // everything it needs to issue its index loads.  Bottom groups run `sub_waves` wavefronts, the top
   // group CELL_WAVES.
   static constexpr int CELL_WAVES = 8, CELL_SLOTS = 8, CELL_STRIDE = 2 * (CELL_WAVES + 1);
-  static constexpr int STAGE_PRODUCTS = 112;  // products of one round (their operands are staged in LDS: 840 B each)
+  static constexpr int STAGE_PRODUCTS = 112;  // products whose operands the kernel stages in LDS at a time (840 B each):
+                                              // a round of up to that many is fetched by all wavefronts together
   int32_t sub_waves = 8;
   std::vector<int32_t> rptr;
   std::vector<int32_t> cells;

@@ -74,6 +74,7 @@ constexpr int LDL_CS = DirectPlan::CELL_SLOTS;
 constexpr int LDL_ST = DirectPlan::CELL_STRIDE;
 constexpr int LDL_NW = DirectPlan::CELL_WAVES;
 constexpr int LDL_STAGE = DirectPlan::STAGE_PRODUCTS;  // products whose operands one piece stages in LDS (92 KB)
+constexpr int LDL_WCH = LDL_STAGE / LDL_NW;             // ... a wavefront's own slice of that, in wide rounds
 
 // sum over the 7 lanes that share this lane's column index c (lanes 7c .. 7c+6)
 __device__ __forceinline__ double ldl_sum_over_r(double v, int c49) {
@@ -296,13 +297,21 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
           else if (lane < 49) lds_raw[wave][t][lane] = acc;  // waits for L(j,j)^-1 (phase C)
         };
         bool started = false;
-        for (int c0 = K0;; c0 += LDL_STAGE) {
-          const int c1 = K1 - c0 < LDL_STAGE ? K1 : c0 + LDL_STAGE;
-          if (c1 > c0) {  // stage products [c0, c1): this wavefront's are c0 + wave, + nw, ...
-            const int pl = c0 + wave + nw * lane;
+        // A round of at most LDL_STAGE products is staged by everybody at once (a level that is one column
+        // with 16 products: eight wavefronts fetch two each).  A wider round has work for every wavefront:
+        // each stages its OWN products, LDL_WCH at a time, in its own slice of the buffers -- no workgroup
+        // barrier, no waiting for the slowest.
+        const bool coop = K1 - K0 <= LDL_STAGE;
+        const int kbw = cell[LDL_NW + 1 + wave + 1];
+        const int P0 = coop ? K0 : ka, P1 = coop ? K1 : kbw, PS = coop ? LDL_STAGE : LDL_WCH;
+        const int sbase = coop ? 0 : wave * LDL_WCH, pstride = coop ? nw : 1, poff = coop ? wave : 0;
+        for (int c0 = P0;; c0 += PS) {
+          const int c1 = P1 - c0 < PS ? P1 : c0 + PS;
+          if (c1 > c0) {  // stage this wavefront's share of products [c0, c1)
+            const int pl = c0 + poff + pstride * lane;
             int ja = 0, jb = 0, jc = 0;
             if (pl < c1) { ja = A.pa[pl]; jb = A.pb[pl]; jc = A.pcol[pl]; }
-            const int cnt = c1 - c0 > wave ? (c1 - c0 - wave + nw - 1) / nw : 0;
+            const int cnt = c1 - c0 > poff ? (c1 - c0 - poff + pstride - 1) / pstride : 0;
             for (int i0 = 0; i0 < cnt; i0 += 4) {
               double va[4], vb[4], vy[4];
 #pragma unroll
@@ -315,13 +324,18 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
                 if (i0 + i < cnt) {
-                  const int slot = wave + nw * (i0 + i);
+                  const int slot = sbase + poff + pstride * (i0 + i);
                   if (lane < 49) { st_a[slot][lane] = va[i]; st_b[slot][lane] = vb[i]; }
                   if (lane < 7) st_y[slot][lane] = vy[i];
                 }
             }
           }
-          __syncthreads();  // (also orders this wavefront's lds_raw rows before its own reads)
+          if (coop) {
+            __syncthreads();  // (also orders this wavefront's lds_raw rows before its own reads)
+          } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
           if (!started) {
             started = true;
             if (n > 0) begin_slot();
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
             // straight from LDS (seven lanes share an address: broadcasts) -- no shuffles; two products of a
             // block at a time where it has two left (a rotating prefetch of product k + 1 cost more in
             // register copies than the LDS round trip it hid: measured)
-            const int sl = k - c0;
+            const int sl = sbase + k - c0;
             if (k + 1 < kend && k + 1 < c1) {  // two products of this block: their reads in flight together
               double am[7], bm[7], am2[7], bm2[7];
 #pragma unroll
@@ -374,8 +388,9 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
             tacc += av * yv;  // (used by diagonal blocks only)
             ++k;
           }
-          if (c1 >= K1) break;
-          __syncthreads();  // everybody is done with this piece before the next one overwrites it
+          if (c1 >= P1) break;
+          if (coop) __syncthreads();  // everybody is done with this piece before the next one overwrites it
+          else __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         if (trace && ti < 254) A.dbg[ti++] = wall_clock64();
