@@ -6,6 +6,7 @@ and a missing GPU makes `Graph.initialize()` raise Sim3OptError(SIM3OPT_ERR_NO_D
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -187,6 +188,16 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not built: run `python -m sim3opt_amd.build` (hipcc, gfx950)")
+        # One HIP runtime per process: libsim3opt.so names the system's libamdhip64, a PyTorch-ROCm wheel
+        # carries its own.  Whichever is mapped first serves both (same soname) -- but if the library were
+        # mapped before torch and torch then initialised its own copy, the library's copy would find the
+        # device taken ("no usable HIP device").  This harness lives next to torch (bench.py, tests): map
+        # torch's first where torch exists.  A C / C++ host that does not use torch is not concerned.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:  # no torch in this interpreter: the system runtime is the only one
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the export is missing
