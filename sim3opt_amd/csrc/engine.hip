@@ -1009,9 +1009,12 @@ class Engine {
   int chi2(double* out, std::string& err, hipEvent_t before_fetch = nullptr, int scale_parts = 0) {
     const int g = grid_for(e_hi - e_lo, WG);
     hipLaunchKernelGGL(k_chi2, dim3(g), dim3(WG), 0, stream, edge_args(), d_part_a);
+    // (exact solver on one GPU: small systems, where the copy of the scalar block is a visible share of a trial)
+    const bool mirror = scale_parts > 0 && use_direct && !comm.active() && !opt.time_kernels;
     if (scale_parts > 0)
       hipLaunchKernelGGL(k_final_sum_two, dim3(1), dim3(WG), 0, stream, (const double*)d_part_a, g, &d_sc->chi2,
-                         (const double*)d_part_b, scale_parts, &d_sc->scale);
+                         (const double*)d_part_b, scale_parts, &d_sc->scale, mirror ? h_sc : (DevScalars*)nullptr,
+                         (const DevScalars*)d_sc);
     else
       hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WG), 0, stream, d_part_a, g, &d_sc->chi2);
     HIPCHK(hipGetLastError());
@@ -1021,7 +1024,8 @@ class Engine {
       if (rc) return rc;
     }
     if (before_fetch) HIPCHK(hipEventRecord(before_fetch, stream));
-    rc = fetch_scalars(err);
+    if (mirror) HIPCHK(hipStreamSynchronize(stream));  // the kernel wrote h_sc's chi2 / scale / fail itself
+    else rc = fetch_scalars(err);
     if (rc) return rc;
     *out = h_sc->chi2;
     kt.n_chi2 += 1;
