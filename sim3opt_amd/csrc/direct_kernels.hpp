@@ -279,7 +279,6 @@ __global__ __launch_bounds__(LDL_WG_TOP) void k_ldl(LdlArgs A, int g0) {
         // is one column with 16 products and seven wavefronts wait at the barrier (round 2).  Now every
         // wavefront fetches its share of ALL the round's operands (four products in flight) into LDS and
         // the owners run their chains of multiply-adds -- the same ones in the same order -- from there.
-        // The host keeps a round within LDL_STAGE products; a block with more is staged piece by piece.
         int t = 0, k = ka, kend = 0, jt = 0;
         bool diag = false;
         double acc = 0.0, tacc = 0.0, bpv = 0.0;
