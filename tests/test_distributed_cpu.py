@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the row-partitioned PCG (CPU).
+"""world_size-2 and -8 gloo tests of the row-partitioned PCG (CPU).
 
 The HIP kernels cannot run here, so this test executes the distributed ALGORITHM the engine uses
 (Engine::pcg in csrc/engine.hip, multi-GPU branch) in numpy, with the engine's own partition
@@ -105,9 +105,10 @@ def _worker(rank, world, port, out):
         np.save(out, x)
 
 
-def test_partitioned_pcg_over_gloo_matches_serial(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_partitioned_pcg_over_gloo_matches_serial(tmp_path, world):
     out = str(tmp_path / "x.npy")
-    _spawn(_worker, 2, out)
+    _spawn(_worker, world, out)
     x = np.load(out)
     H, b = _block_system()
     lam = 1e-5 * np.abs(np.diag(H)).max()
@@ -250,9 +251,10 @@ def _amg_worker(rank, world, port, out):
         np.savez(out, x=x, it=it)
 
 
-def test_partitioned_multigrid_pcg_over_gloo_matches_serial(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_partitioned_multigrid_pcg_over_gloo_matches_serial(tmp_path, world):
     out = str(tmp_path / "amg.npz")
-    _spawn(_amg_worker, 2, out)
+    _spawn(_amg_worker, world, out)
     res = np.load(out)
     H, b, P = _amg_system()
     n = H.shape[0]
