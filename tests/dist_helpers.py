@@ -1,8 +1,65 @@
 """torch.distributed (gloo) implementations of the library's host-collective callbacks, shared by
-the CPU emulation test and the 2-process GPU test."""
+the CPU emulation test and the 2-process GPU test; and the same callbacks for ranks that are THREADS
+of one process (ThreadGroup) -- a GPU box admits six processes on its card, threads are not counted,
+so that is how the 8-rank partition runs the real kernels."""
+import threading
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+class ThreadGroup:
+    """Host collectives among `world` threads of this process: every rank leaves its staging buffer in a
+    slot, a barrier, everybody reduces in rank order (the same bits on every rank) or copies the other
+    ranks' segments, a barrier.  A rank that fails aborts the barrier, so nobody hangs."""
+
+    def __init__(self, world, timeout=600.0):
+        self.world = world
+        self.timeout = timeout
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def allreduce(self, rank):
+        def f(arr, op):
+            self.slots[rank] = arr
+            self.bar.wait(self.timeout)
+            res = self.slots[0].copy()
+            for r in range(1, self.world):
+                res = np.maximum(res, self.slots[r]) if op == 1 else res + self.slots[r]
+            self.bar.wait(self.timeout)  # everybody has read every slot
+            arr[:] = res
+        return f
+
+    def allgatherv(self, rank):
+        def f(arr, offs, rk):
+            self.slots[rank] = arr
+            self.bar.wait(self.timeout)
+            for r in range(self.world):
+                if r != rank and offs[r + 1] > offs[r]:
+                    arr[int(offs[r]):int(offs[r + 1])] = self.slots[r][int(offs[r]):int(offs[r + 1])]
+            self.bar.wait(self.timeout)
+        return f
+
+    def run(self, target):
+        """target(rank) -> result, one thread per rank; re-raises the first failure."""
+        out, err = [None] * self.world, []
+
+        def body(rank):
+            try:
+                out[rank] = target(rank)
+            except BaseException as e:  # noqa: BLE001 -- reported below
+                err.append(e)
+                self.bar.abort()
+
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
 
 
 def allreduce(arr, op):

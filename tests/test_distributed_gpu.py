@@ -184,20 +184,8 @@ def _worker_cfg3(rank, world, port, out):
              rmse_gt=synth.rmse(G.get_vertices(), g["gt"]), rmse_gt0=synth.rmse(g["states"], g["gt"]))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_config4_full_size_graph_row_partitioned(tmp_path, monkeypatch, world):
-    """BASELINE.json configs[3]: the 100k-vertex / 1M-edge Manhattan graph row-partitioned over 2 and 4
-    ranks (here: processes sharing the one GPU -- the box allows six processes on its card, the test
-    runner included, so 8 ranks cannot run here; the plan for 8 is checked on the host in
-    test_host.py::test_locality_order_and_halo_of_the_row_partition --, host-staged collectives; the kernels, the partition, the halo exchange and the collective
-    sequence are those of the RCCL path -- N > 1 on xGMI itself is unmeasured on hardware).  Same
-    property checks as the single-GPU config-3 test, plus rank agreement, the halo plan and the
-    single-process chi2 trace."""
+def _check_cfg3(res, world, monkeypatch):
     from sim3opt_amd import lib as L, synth
-    out = str(tmp_path / "c")
-    H.spawn_with_port_retry(
-        lambda: mp.spawn(_worker_cfg3, args=(world, _free_port(), out), nprocs=world, join=True))
-    res = [np.load(out + f".{r}.npz") for r in range(world)]
     nb = 99999
     assert res[0]["rows"][0] == 0 and res[-1]["rows"][1] == nb
     for a, b in zip(res[:-1], res[1:]):
@@ -232,3 +220,53 @@ def test_config4_full_size_graph_row_partitioned(tmp_path, monkeypatch, world):
     # a lightly damped solve ends a few iterations earlier or later, measured 30 against 26)
     assert all(abs(int(a) - int(s.pcg_iters)) <= 8 for a, s in zip(r0["pcg"], st)), (
         list(r0["pcg"]), [s.pcg_iters for s in st])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_config4_full_size_graph_row_partitioned(tmp_path, monkeypatch, world):
+    """BASELINE.json configs[3]: the 100k-vertex / 1M-edge Manhattan graph row-partitioned over 2 and 4
+    ranks (here: processes sharing the one GPU -- the box allows six processes on its card, the test
+    runner included: the 8-rank case runs as threads, test_config4_full_size_graph_row_partitioned_over_8_ranks below --, host-staged collectives; the kernels, the partition, the halo exchange and the collective
+    sequence are those of the RCCL path -- N > 1 on xGMI itself is unmeasured on hardware).  Same
+    property checks as the single-GPU config-3 test, plus rank agreement, the halo plan and the
+    single-process chi2 trace."""
+    from sim3opt_amd import lib as L, synth
+    out = str(tmp_path / "c")
+    H.spawn_with_port_retry(
+        lambda: mp.spawn(_worker_cfg3, args=(world, _free_port(), out), nprocs=world, join=True))
+    res = [np.load(out + f".{r}.npz") for r in range(world)]
+    _check_cfg3(res, world, monkeypatch)
+
+
+def test_config4_full_size_graph_row_partitioned_over_8_ranks(monkeypatch):
+    """The same with EIGHT ranks -- threads of this process, each with its own graph handle, engine and HIP
+    stream, host collectives through dist_helpers.ThreadGroup (the box counts processes on its card, not
+    threads): the 8-rank partition of config 4 with the real kernels, halo exchange and collective
+    sequence."""
+    from sim3opt_amd import lib as L, synth
+    world = 8
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan()
+    tg = H.ThreadGroup(world)
+
+    def rank_body(rank):
+        G = L.Graph(device=0, fix_small_angle_b=1, pcg_rel_tol=1e-8)
+        G.add_vertices(g["states"], g["fixed"])
+        G.add_edges(g["v0"], g["v1"], g["meas"])
+        G.comm_init_callbacks(rank, world, tg.allreduce(rank), tg.allgatherv(rank))
+        G.initialize()
+        lo, hi = G.local_rows()
+        chi0 = G.chi2()
+        n = G.optimize(3)
+        st = G.stats()
+        _, _, bnd, cut = G.partition_plan(world)
+        V = G.get_vertices()
+        res = dict(pos=synth.positions(V), scale=V[:, 7].copy(), chi0=chi0, n=n, rows=[lo, hi],
+                   prec=G.preconditioner_in_use(), n_halo=int(bnd.sum()), cut_edges=cut,
+                   chi=[s.chi2_after for s in st], trials=[s.trials for s in st], pcg=[s.pcg_iters for s in st],
+                   rel=[s.pcg_rel_res for s in st], rmse_gt=synth.rmse(V, g["gt"]),
+                   rmse_gt0=synth.rmse(g["states"], g["gt"]))
+        G.close()
+        return res
+
+    _check_cfg3(tg.run(rank_body), world, monkeypatch)
