@@ -53,3 +53,33 @@ for t in range(1, 7):
     res = np.linalg.norm(rhs - A @ xp) / np.linalg.norm(rhs)
     _, it_proj, _ = pcg(A, rhs, M, 1e-8, 400, x0=xp, rz_ref=rzref)
     print("trial %d: lambda %.3g (%.1e x mean diag): cold %d, warm(prev x) %d, projected %d its (rel residual of projection %.2e)" % (t, lam, lam / dmean, it_cold, it_warm, it_proj, res))
+
+# ---- deflation with the lowest Ritz vectors of the first solve's basis (Saad, Yeung, Erhel, Guyomarc'h 2000) ----
+import scipy.linalg as sla
+def deflated_pcg(A, b, M, W, AW, tol, maxit, rz_ref):
+    G = W.T @ AW
+    Gi = np.linalg.inv(G)
+    x = W @ (Gi @ (W.T @ b))
+    r = b - A @ x
+    z = M(r)
+    p = z - W @ (Gi @ (AW.T @ z))
+    rz = r @ z
+    if rz <= tol * tol * rz_ref: return x, 0
+    for it in range(1, maxit + 1):
+        q = A @ p; alpha = rz / (p @ q); x += alpha * p; r -= alpha * q
+        z = M(r); rzn = r @ z
+        if rzn <= tol * tol * rz_ref: return x, it
+        p = z + (rzn / rz) * p - W @ (Gi @ (AW.T @ z)); rz = rzn
+    return x, maxit
+th, Y = sla.eigh(G1 + lam0 * G2, G2)
+print("lowest Ritz values of H + lambda0 in the basis:", np.array2string(th[:10], precision=3))
+for kdef in (4, 8, 16):
+    W = Vb @ Y[:, :kdef]
+    HW = H @ W
+    lam = lam0; nu = 2.0; out = []
+    for t in range(1, 6):
+        lam *= nu; nu *= 2
+        A, M = setup(lam)
+        _, itd = deflated_pcg(A, rhs, M, W, HW + lam * W, 1e-8, 400, rzref)
+        out.append(itd)
+    print("deflating the %d lowest Ritz vectors: trials 1..5 need %s iterations" % (kdef, out))
