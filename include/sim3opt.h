@@ -88,6 +88,44 @@ typedef struct sim3opt_options {
                                             GPU, at most ~3e5 7x7x7 block products per factorisation:
                                             KITTI-00 and other chain-like graphs) and no
                                             `preconditioner` was named, else the PCG                */
+  /* ---- tuning of the PCG path that changes its NUMERICS (iteration counts, summation orders; the
+   * solution it converges to is the same).  Read by sim3opt_initialize.  0 / negative = the default
+   * rule where stated.  A SIM3OPT_* environment variable of the same name overrides the field at
+   * sim3opt_initialize (debug aid); sim3opt_get_options then reports the value that was used. ---- */
+  int32_t amg_cycle[4];     /* 0,..  visits of multigrid level 1, 2, 3, >= 4 per visit of the level above
+                                        (1 = V, 2 = W, 3); all 0 = automatic: {2,3,3,3}, or {1,2,2,2} when level 0
+                                        is partitioned over >= 4 ranks (the coarse cycle is what stays
+                                        latency-bound when level 0 is sharded)  [SIM3OPT_AMG_CYCLE] */
+  int32_t amg_passes[3];    /* 0,..  pairwise-matching passes on level 0, 1, >= 2 (aggregates of 2^passes rows);
+                                        0 = automatic: 3, or 2 on level 0 of a graph that reaches the dense level
+                                        that way                                              [SIM3OPT_AMG_PASSES] */
+  int32_t amg_additive;     /* 0     1: additive level 0 (no level-0 matrix pass in the cycle) [SIM3OPT_AMG_ADDITIVE] */
+  int32_t amg_fp32;         /* 1     the cycle's matrix passes stream FP32 copies of the blocks [SIM3OPT_AMG_FP32] */
+  int32_t amg_pivot;        /* 14    pivot rows of the dense coarsest inverse (14 or 28)       [SIM3OPT_AMG_PIVOT] */
+  int32_t amg_coarsest;     /* 256   most block rows of the dense coarsest level (8..256)      [SIM3OPT_AMG_COARSEST] */
+  int32_t adaptive_prec;    /* 1     automatic preconditioner only: damping-dominated solves start with
+                                        block-Jacobi (DESIGN.md 5a')                           [SIM3OPT_ADAPTIVE_PREC] */
+  int32_t row_order;        /* -1    block-row order: 0 = insertion (g2o's hessianIndex), 1 = breadth-first
+                                        locality order, -1 = automatic (insertion on one rank, locality order
+                                        when partitioned)                                      [SIM3OPT_ROW_ORDER=insertion|bfs] */
+  int32_t halo_exchange;    /* 1     partitioned runs exchange boundary rows only; 0 = whole-vector all-gather
+                                                                                               [SIM3OPT_NO_HALO] */
+  int32_t span_grid;        /* 0     workgroups of the span SpMV; 0 = automatic                [SIM3OPT_SPAN_GRID] */
+  int32_t force_collectives;/* 0     1: run every collective of the partitioned path even with one rank
+                                        (transport self-test)                                  [SIM3OPT_FORCE_COMM] */
+  int32_t amg_shard_rows;   /* 4096  partitioned runs: multigrid levels with more block rows than this are
+                                        partitioned by owner like level 0 (aggregates never straddle ranks), smaller
+                                        ones are replicated                                    [SIM3OPT_AMG_SHARD_ROWS] */
+  int32_t amg_virtual_ranks;/* 0     > 1 on ONE rank: build the hierarchy as an N-rank partition would (aggregates
+                                        inside N equal row spans): what a partitioned run is compared with
+                                                                                               [SIM3OPT_AMG_VIRTUAL_RANKS] */
+  int32_t pcg_batch;        /* 0     most right-hand sides solved together when LM trials are rejected in a row
+                                        (DESIGN.md 5d); 0 = automatic, 1 = one at a time          [SIM3OPT_PCG_BATCH] */
+  double amg_omega;         /* 0.9   damping of the block-Jacobi smoother (0.1..0.95)          [SIM3OPT_AMG_OMEGA] */
+  double amg_over[2];       /* 1.8, 1.6  over-correction of the coarse correction prolonged into level 0 / into
+                                        deeper levels                                          [SIM3OPT_AMG_OVER=a0,a1] */
+  int64_t direct_max_pairs; /* 0     most 7x7x7 block products of a factorisation the automatic rule accepts;
+                                        0 = 300000 (3e7 with linear_solver = 1)               [SIM3OPT_DIRECT_MAX_PAIRS] */
 } sim3opt_options;
 
 /* Per-iteration record (g2o G2OBatchStatistics role; bal_example.cpp:55-56). */
@@ -104,6 +142,13 @@ typedef struct sim3opt_iter_stats {
                          * markers per trial are 7 % of a KITTI-00 iteration) */
   double ms_solve;
   double ms_update;     /* oplus + chi2 + scale                */
+  int32_t pcg_capped;   /* PCG solves of this iteration that stopped at pcg_max_iters without reaching
+                         * pcg_rel_tol.  LinearSolverEigen (kitti_surf.cpp:553-554) has no such state; a
+                         * capped solve is an INEXACT LM step, not a failed one: CG iterates from x0 = 0 are
+                         * descent directions of the damped model and satisfy x.(lambda x + b) = x.(H+lambda I)x,
+                         * so g2o's gain ratio stays meaningful and decides the trial.  Exact
+                         * solver: always 0 */
+  int32_t reserved_;
 } sim3opt_iter_stats;
 
 /* Device time of the dominant kernels accumulated since initialize / reset
@@ -122,6 +167,8 @@ typedef struct sim3opt_kernel_times {
 typedef struct sim3opt_comm_times {
   double ms_allreduce;  int64_t n_allreduce;  int64_t bytes_allreduce;
   double ms_allgather;  int64_t n_allgather;  int64_t bytes_allgather;
+  /* neighbour exchanges (grouped send / receive pairs); bytes: what THIS rank sent plus what it received */
+  double ms_exchange;   int64_t n_exchange;   int64_t bytes_exchange;
 } sim3opt_comm_times;
 
 int sim3opt_version(void);
@@ -258,6 +305,14 @@ typedef int (*sim3opt_allgatherv_fn)(void* ctx, double* buf, const int64_t* offs
 int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
                                 sim3opt_allreduce_fn allreduce, sim3opt_allgatherv_fn allgatherv,
                                 void* ctx);
+/* Optional third callback: the neighbour exchange of the partitioned path (halo rows of a level go to the
+ * ranks that read them and to nobody else).  send[send_offsets[p] .. send_offsets[p+1]) goes to rank p,
+ * recv[recv_offsets[p] .. recv_offsets[p+1]) must hold what rank p sent to this rank on return (offsets
+ * in doubles, world+1 entries each; most spans are empty: a slab has two neighbours).  Without it the
+ * library falls back to the all-gather of the whole vector.  Call after sim3opt_comm_init_callbacks. */
+typedef int (*sim3opt_alltoallv_fn)(void* ctx, const double* send, const int64_t* send_offsets, double* recv,
+                                    const int64_t* recv_offsets, int32_t rank, int32_t world);
+int sim3opt_comm_set_alltoallv(sim3opt_graph* g, sim3opt_alltoallv_fn alltoallv);
 /* Plan of the per-iteration exchange for `n_block_rows` rows over `world` ranks (host only): fills
  * row_begin (world+1, may be NULL) with the equal-length rank partition and returns 1 when the
  * in-place equal-count ncclAllGather applies (always, for this partition -- trailing ranks may be

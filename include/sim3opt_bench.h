@@ -15,11 +15,14 @@ int sim3opt_bench_spmv(sim3opt_graph* g, int32_t reps, double* ms_mean);
 /* HBM read calibration over the same value array (bench only): mode 0 = 16 B/lane contiguous,
  * 1 = 8 B/lane contiguous, 2 = 8 B/lane on 49 of 64 lanes per 392-B block (the SpMV's shape) */
 int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* ms_mean);
-/* Measurement prototype, not on the product path: the two-phase SpMV over upper-triangle storage
- * (csrc/symm_proto.hpp) on the last linearisation.  out[0] / out[1]: mean ms of phase 1 / phase 2 over
+#ifdef SIM3OPT_BENCH_HOOKS
+/* Measurement prototype, NOT exported by the product library (only by a SIM3OPT_BENCH_HOOKS build,
+ * csrc/engine_proto.hip): the two-phase SpMV over upper-triangle storage (csrc/symm_proto.hpp) on the
+ * last linearisation.  out[0] / out[1]: mean ms of phase 1 / phase 2 over
  * `reps` launches, out[2]: max difference to the product SpMV relative to max |q|, out[3]: bytes of its
  * stream.  Single GPU. */
 int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]);
+#endif
 
 #ifdef __cplusplus
 }

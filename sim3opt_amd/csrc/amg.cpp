@@ -41,7 +41,8 @@ WGraph graph_from_pattern(int32_t nb, const int32_t* rowptr, const int32_t* coli
 }
 
 // One pass of greedy heavy-edge matching in natural order; returns the number of clusters.
-int32_t match_pass(const WGraph& g, std::vector<int32_t>& cid) {
+// owner (may be null): rank that owns every node; nodes of different ranks are never clustered together
+int32_t match_pass(const WGraph& g, std::vector<int32_t>& cid, const int32_t* owner) {
   const int32_t m = g.n();
   std::vector<int32_t> match(m, -1);
   for (int32_t i = 0; i < m; ++i) {
@@ -50,6 +51,7 @@ int32_t match_pass(const WGraph& g, std::vector<int32_t>& cid) {
     int64_t bw = 0;
     for (int32_t k = g.ptr[i]; k < g.ptr[i + 1]; ++k) {
       const int32_t j = g.nbr[k];
+      if (owner && owner[j] != owner[i]) continue;
       if (match[j] < 0 && g.wgt[k] > bw) {
         best = j;
         bw = g.wgt[k];
@@ -75,6 +77,7 @@ int32_t match_pass(const WGraph& g, std::vector<int32_t>& cid) {
     int32_t best = -1;
     int64_t bw = 0;
     for (int32_t k = g.ptr[i]; k < g.ptr[i + 1]; ++k) {
+      if (owner && owner[g.nbr[k]] != owner[i]) continue;
       const int32_t c = rep[g.nbr[k]];
       if (c != i && csize[c] < 4 && g.wgt[k] > bw) {
         best = c;
@@ -125,17 +128,17 @@ WGraph coarsen_graph(const WGraph& g, const std::vector<int32_t>& cid, int32_t n
 }  // namespace
 
 bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* colidx0,
-                         std::vector<AmgLevelHost>& levels, std::string& why) {
+                         std::vector<AmgLevelHost>& levels, std::string& why, const AmgBuildOptions& bo) {
   levels.clear();
   levels.emplace_back();
   levels[0].nb = nb0;
   levels[0].nnzb = rowptr0[nb0];
+  const bool parted = bo.world > 1 && bo.row_begin != nullptr;
+  if (parted) levels[0].row_begin.assign(bo.row_begin, bo.row_begin + bo.world + 1);
   const int32_t* rowptr = rowptr0;
   const int32_t* colidx = colidx0;
   std::vector<int64_t> bw, bw_next;  // level-0 blocks behind each block of the current level
-  int max_coarsest = AMG_MAX_COARSEST;
-  if (const char* ev = std::getenv("SIM3OPT_AMG_COARSEST"))  // tuning knob
-    max_coarsest = std::max(8, std::min(AMG_MAX_COARSEST, std::atoi(ev)));
+  const int max_coarsest = std::max(8, std::min(AMG_MAX_COARSEST, bo.max_coarsest > 0 ? bo.max_coarsest : AMG_MAX_COARSEST));
   for (;;) {
     AmgLevelHost& L = levels.back();
     const int32_t nb = L.nb;
@@ -152,14 +155,26 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
     // aggregates of 8 (3 passes); graphs small enough for two levels with aggregates of 4 take those:
     // on KITTI-00 (770 rows -> 192 dense) a third of the PCG iterations (measured)
     int npass = levels.size() == 1 && nb <= 4 * max_coarsest ? 2 : 3;
-    if (const char* ev = std::getenv("SIM3OPT_AMG_PASSES")) {  // tuning knob: passes per level, e.g. "344"
-      const size_t l = std::min(levels.size() - 1, std::strlen(ev) - 1);
-      if (std::strlen(ev) > 0 && ev[l] >= '1' && ev[l] <= '6') npass = ev[l] - '0';
+    {
+      const int32_t p = bo.passes[std::min<size_t>(levels.size() - 1, 2)];  // tuning knob: passes per level
+      if (p >= 1 && p <= 6) npass = p;
+    }
+    // owner of every node of the (repeatedly coarsened) matching graph: clusters stay inside one rank's span
+    std::vector<int32_t> owner;
+    if (parted) {
+      owner.resize(nb);
+      for (int32_t r = 0; r < bo.world; ++r)
+        for (int32_t i = L.row_begin[r]; i < L.row_begin[r + 1]; ++i) owner[i] = r;
     }
     for (int pass = 0; pass < npass && nc > max_coarsest / 2; ++pass) {
       std::vector<int32_t> cid;
-      const int32_t m = match_pass(g, cid);
+      const int32_t m = match_pass(g, cid, parted ? owner.data() : nullptr);
       for (int32_t& a : agg) a = cid[a];
+      if (parted) {
+        std::vector<int32_t> oc(m);
+        for (int32_t i = 0; i < (int32_t)cid.size(); ++i) oc[cid[i]] = owner[i];
+        owner.swap(oc);
+      }
       g = coarsen_graph(g, cid, m);
       nc = m;
     }
@@ -191,6 +206,16 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
     });
     AmgLevelHost C;
     C.nb = nc;
+    if (parted) {  // clusters are numbered by their smallest row and never straddle: contiguous spans again
+      C.row_begin.assign(bo.world + 1, 0);
+      for (int32_t a = 0; a < nc; ++a) ++C.row_begin[owner[a] + 1];
+      for (int32_t r = 0; r < bo.world; ++r) C.row_begin[r + 1] += C.row_begin[r];
+      for (int32_t a = 1; a < nc; ++a)
+        if (owner[a] < owner[a - 1]) {
+          why = "internal: coarse ownership is not contiguous";
+          return false;
+        }
+    }
     C.rowptr.assign(nc + 1, 0);
     L.gblk.resize(ents.size());
     L.grow.resize(ents.size());

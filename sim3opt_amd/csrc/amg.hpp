@@ -29,6 +29,18 @@ struct AmgLevelHost {
   std::vector<int32_t> mptr, mem;  // coarse nb + 1, nb: rows of each aggregate, ascending
   std::vector<int32_t> gptr;       // coarse nnzb + 1: contributions to each coarse block ...
   std::vector<int32_t> gblk, grow; // ... as (block index, block row) of THIS level, ascending block index
+  // row partition of this level over the ranks (world + 1 entries; empty: one rank).  Aggregates never
+  // straddle two ranks and are numbered by their smallest row, so every level's spans are contiguous and
+  // a rank's coarse rows are exactly the aggregates of its own fine rows: Galerkin products and
+  // restrictions need no reduction across ranks
+  std::vector<int32_t> row_begin;
+};
+
+struct AmgBuildOptions {
+  int32_t max_coarsest = 256;       // most rows of the dense coarsest level (8 .. AMG_MAX_COARSEST)
+  int32_t passes[3] = {0, 0, 0};    // matching passes on level 0, 1, >= 2; 0 = automatic
+  int32_t world = 1;                // ranks of the row partition the aggregation must respect
+  const int32_t* row_begin = nullptr;  // world + 1: level-0 spans (required when world > 1)
 };
 
 constexpr int AMG_MAX_COARSEST = 256;  // block rows of the dense coarsest level (1792 unknowns)
@@ -37,6 +49,7 @@ constexpr int AMG_MAX_LEVELS = 10;
 // Builds the level patterns from the level-0 block-CSR pattern.  Returns false (with a reason)
 // when the graph does not coarsen to AMG_MAX_COARSEST rows, e.g. star-like graphs.
 bool build_amg_hierarchy(int32_t nb, const int32_t* rowptr, const int32_t* colidx,
-                         std::vector<AmgLevelHost>& levels, std::string& why);
+                         std::vector<AmgLevelHost>& levels, std::string& why,
+                         const AmgBuildOptions& bo = AmgBuildOptions());
 
 }  // namespace sim3opt

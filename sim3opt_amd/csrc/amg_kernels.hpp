@@ -550,3 +550,12 @@ __global__ __launch_bounds__(WG) void k_amg_dense_apply(int n, const double* __r
     if (lane == 0) x[i] = acc;
   }
 }
+
+// FP32 copy of a block array (the multigrid's matrix passes read it)
+__global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restrict__ src,
+                                               float* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+    dst[f32_pair_index((int64_t)(i / 49), (int)(i % 49))] = (float)src[i];
+}
+
+

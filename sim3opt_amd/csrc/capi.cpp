@@ -142,6 +142,58 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->verbose = 0;
   o->time_kernels = 0;
   o->linear_solver = -1;
+  for (int32_t& v : o->amg_cycle) v = 0;
+  for (int32_t& v : o->amg_passes) v = 0;
+  o->amg_additive = 0;
+  o->amg_fp32 = 1;
+  o->amg_pivot = 14;
+  o->amg_coarsest = 256;
+  o->adaptive_prec = 1;
+  o->row_order = -1;
+  o->halo_exchange = 1;
+  o->span_grid = 0;
+  o->force_collectives = 0;
+  o->amg_shard_rows = 4096;
+  o->amg_virtual_ranks = 0;
+  o->pcg_batch = 0;
+  o->amg_omega = 0.9;
+  o->amg_over[0] = 1.8;
+  o->amg_over[1] = 1.6;
+  o->direct_max_pairs = 0;
+}
+
+// Debug overrides: a SIM3OPT_* environment variable replaces the option field of the same name when the
+// graph is initialised (tests and tuning scripts drive the library that way); the override lands in the
+// handle's options, so sim3opt_get_options reports what was used.
+static void apply_env_overrides(sim3opt_options& o) {
+  auto digits = [](const char* ev, int32_t* dst, int n, int lo, int hi) {
+    int last = 0;
+    const int len = (int)std::strlen(ev);
+    for (int l = 0; l < n; ++l) {
+      if (l < len && ev[l] - '0' >= lo && ev[l] - '0' <= hi) last = ev[l] - '0';
+      dst[l] = last;
+    }
+  };
+  if (const char* ev = std::getenv("SIM3OPT_AMG_CYCLE")) digits(ev, o.amg_cycle, 4, 1, 3);    // "122": levels 1, 2, 3...
+  if (const char* ev = std::getenv("SIM3OPT_AMG_PASSES")) digits(ev, o.amg_passes, 3, 1, 6);  // "344"
+  if (const char* ev = std::getenv("SIM3OPT_AMG_ADDITIVE")) o.amg_additive = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SIM3OPT_AMG_FP32")) o.amg_fp32 = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SIM3OPT_AMG_PIVOT")) o.amg_pivot = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_AMG_COARSEST")) o.amg_coarsest = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_ADAPTIVE_PREC")) o.adaptive_prec = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SIM3OPT_ROW_ORDER")) o.row_order = std::string(ev) == "bfs" ? 1 : 0;
+  if (std::getenv("SIM3OPT_NO_HALO")) o.halo_exchange = 0;
+  if (const char* ev = std::getenv("SIM3OPT_SPAN_GRID")) o.span_grid = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_FORCE_COMM")) o.force_collectives = ev[0] == '1';
+  if (const char* ev = std::getenv("SIM3OPT_AMG_SHARD_ROWS")) o.amg_shard_rows = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_AMG_VIRTUAL_RANKS")) o.amg_virtual_ranks = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_PCG_BATCH")) o.pcg_batch = std::atoi(ev);
+  if (const char* ev = std::getenv("SIM3OPT_AMG_OMEGA")) o.amg_omega = std::atof(ev);
+  if (const char* ev = std::getenv("SIM3OPT_AMG_OVER")) {  // "a0[,a1]": the last value repeats
+    o.amg_over[0] = o.amg_over[1] = std::atof(ev);
+    if (const char* c = std::strchr(ev, ',')) o.amg_over[1] = std::atof(c + 1);
+  }
+  if (const char* ev = std::getenv("SIM3OPT_DIRECT_MAX_PAIRS")) o.direct_max_pairs = std::atoll(ev);
 }
 
 sim3opt_graph* sim3opt_create(void) {
@@ -164,7 +216,8 @@ void sim3opt_release_device_cache(void) { sim3opt::dev_cache_release(); }
 int sim3opt_set_options(sim3opt_graph* g, const sim3opt_options* o) {
   if (!g || !o) return fail(g, SIM3OPT_ERR_ARG, "set_options: null argument");
   if (!(o->fd_delta > 0) || !(o->exp_eps > 0) || o->max_trials < 1 || !(o->pcg_rel_tol >= 0) ||
-      !(o->tau > 0) || o->pcg_check_every < 0)
+      !(o->tau > 0) || o->pcg_check_every < 0 || o->amg_virtual_ranks < 0 || o->pcg_batch < 0 ||
+      o->direct_max_pairs < 0 || !(o->amg_omega > 0) || !(o->amg_over[0] > 0) || !(o->amg_over[1] > 0))
     return fail(g, SIM3OPT_ERR_ARG, "set_options: value out of range");
   g->opt = *o;
   if (g->engine) engine_set_options(g->engine, g->opt);
@@ -287,9 +340,9 @@ int sim3opt_initialize(sim3opt_graph* g) {
   {
     // a graph that is row-partitioned over several ranks gets its block rows in locality order
     // (contiguous rank spans are then slabs of the graph: few cut edges, a small halo); one rank
-    // keeps g2o's insertion order.  SIM3OPT_ROW_ORDER=bfs / insertion overrides (tests, measurements).
-    bool local = g->comm_set && g->comm.world > 1;
-    if (const char* ev = std::getenv("SIM3OPT_ROW_ORDER")) local = std::string(ev) == "bfs";
+    // keeps g2o's insertion order (options.row_order overrides: tests, measurements).
+    apply_env_overrides(g->opt);
+    const bool local = g->opt.row_order >= 0 ? g->opt.row_order == 1 : (g->comm_set && g->comm.world > 1);
     std::vector<int32_t> order;
     if (local) locality_order(g->host, order);
     if (!build_structure(g->host, g->structure, g->err, local ? &order : nullptr)) return SIM3OPT_ERR_STATE;
@@ -557,11 +610,13 @@ int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* m
   return engine_bench_stream(g->engine, mode, reps, ms_mean, g->err);
 }
 
+#ifdef SIM3OPT_BENCH_HOOKS  // (measurement prototype: not in the product library, see engine_proto.hip)
 int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]) {
   if (!g || !out || reps < 1) return fail(g, SIM3OPT_ERR_ARG, "bench_spmv_symmetric: bad argument");
   if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv_symmetric: call sim3opt_initialize first");
   return engine_bench_spmv_symmetric(g->engine, reps, out, g->err);
 }
+#endif
 
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,
                            int32_t* row_begin) {
@@ -596,10 +651,10 @@ int sim3opt_comm_unique_id(uint8_t id_out[128]) {
 int sim3opt_comm_init(sim3opt_graph* g, int32_t rank, int32_t world, const uint8_t unique_id[128]) {
   if (!g || world < 1 || rank < 0 || rank >= world) return fail(g, SIM3OPT_ERR_ARG, "comm_init: bad rank/world");
   if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_init: call before sim3opt_initialize");
-  // SIM3OPT_FORCE_COMM=1: build the communicator and run every collective even with one rank
+  // options.force_collectives: build the communicator and run every collective even with one rank
   // (self-test of the RCCL transport on a single-GPU machine)
-  const char* fc = std::getenv("SIM3OPT_FORCE_COMM");
-  const bool force = fc && fc[0] == '1';
+  apply_env_overrides(g->opt);
+  const bool force = g->opt.force_collectives != 0;
   if (world == 1 && !force) return SIM3OPT_OK;
   if (!unique_id) return fail(g, SIM3OPT_ERR_ARG, "comm_init: null unique id");
   if (g->opt.device >= 0 && hipSetDevice(g->opt.device) != hipSuccess)
@@ -625,6 +680,14 @@ int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
   g->comm.cb_allgatherv = allgatherv;
   g->comm.cb_ctx = ctx;
   g->comm_set = world > 1;
+  return SIM3OPT_OK;
+}
+
+int sim3opt_comm_set_alltoallv(sim3opt_graph* g, sim3opt_alltoallv_fn alltoallv) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (g->initialized) return fail(g, SIM3OPT_ERR_STATE, "comm_set_alltoallv: call before sim3opt_initialize");
+  if (g->comm.kind != 2) return fail(g, SIM3OPT_ERR_STATE, "comm_set_alltoallv: call sim3opt_comm_init_callbacks first");
+  g->comm.cb_alltoallv = alltoallv;
   return SIM3OPT_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -22,6 +23,8 @@ struct RcclApi {
                             hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -55,6 +58,8 @@ bool load_rccl(std::string& err) {
   LOAD(AllReduce, "ncclAllReduce")
   LOAD(Broadcast, "ncclBroadcast")
   LOAD(AllGather, "ncclAllGather")
+  LOAD(Send, "ncclSend")
+  LOAD(Recv, "ncclRecv")
   LOAD(GroupStart, "ncclGroupStart")
   LOAD(GroupEnd, "ncclGroupEnd")
   LOAD(GetErrorString, "ncclGetErrorString")
@@ -140,7 +145,9 @@ int Comm::drain(std::string& err) {
   for (size_t i = 0; i + 1 < ev_used; i += 2) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-    if (ev_kind[i / 2] == 0) times.ms_allreduce += ms; else times.ms_allgather += ms;
+    if (ev_kind[i / 2] == 0) times.ms_allreduce += ms;
+    else if (ev_kind[i / 2] == 1) times.ms_allgather += ms;
+    else times.ms_exchange += ms;
   }
   ev_used = 0;
   return SIM3OPT_OK;
@@ -168,6 +175,62 @@ int Comm::allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t
   times.n_allgather += 1;
   times.bytes_allgather += (int64_t)sizeof(double) * offs[world];
   return stamp(1, false, stream, err);
+}
+
+int Comm::exchange(const double* sbuf, const std::vector<int64_t>& soffs, double* rbuf,
+                   const std::vector<int64_t>& roffs, hipStream_t stream, std::string& err) {
+  if (!active()) return SIM3OPT_OK;
+  if (!timing) return exchange_impl(sbuf, soffs, rbuf, roffs, stream, err);
+  int rc = stamp(2, true, stream, err);
+  if (rc) return rc;
+  rc = exchange_impl(sbuf, soffs, rbuf, roffs, stream, err);
+  if (rc) return rc;
+  times.n_exchange += 1;
+  times.bytes_exchange += (int64_t)sizeof(double) * (soffs[world] + roffs[world]);
+  return stamp(2, false, stream, err);
+}
+
+int Comm::exchange_impl(const double* sbuf, const std::vector<int64_t>& soffs, double* rbuf,
+                        const std::vector<int64_t>& roffs, hipStream_t stream, std::string& err) {
+  if (kind == 1) {
+    NCCLCHK(g_api.GroupStart());
+    for (int p = 0; p < world; ++p) {
+      const size_t ns = (size_t)(soffs[p + 1] - soffs[p]), nr = (size_t)(roffs[p + 1] - roffs[p]);
+      ncclResult_t rr = ncclSuccess;
+      if (ns) rr = g_api.Send(sbuf + soffs[p], ns, ncclFloat64, p, (ncclComm_t)nccl, stream);
+      if (rr == ncclSuccess && nr) rr = g_api.Recv(rbuf + roffs[p], nr, ncclFloat64, p, (ncclComm_t)nccl, stream);
+      if (rr != ncclSuccess) {
+        (void)g_api.GroupEnd();
+        err = std::string("ncclSend / ncclRecv: ") + g_api.GetErrorString(rr);
+        return SIM3OPT_ERR_COMM;
+      }
+    }
+    NCCLCHK(g_api.GroupEnd());
+    return SIM3OPT_OK;
+  }
+  if (!cb_alltoallv) {
+    err = "neighbour exchange without an alltoallv callback";
+    return SIM3OPT_ERR_COMM;
+  }
+  const size_t ns = (size_t)soffs[world], nr = (size_t)roffs[world];
+  int rc = ensure_stage(*this, std::max<size_t>(ns, 1), err);
+  if (rc) return rc;
+  if (h_stage2_len < std::max<size_t>(nr, 1)) {
+    if (h_stage2) (void)hipHostFree(h_stage2);
+    h_stage2 = nullptr;
+    h_stage2_len = 0;
+    HIPCHK(hipHostMalloc((void**)&h_stage2, sizeof(double) * std::max<size_t>(nr, 1)));
+    h_stage2_len = std::max<size_t>(nr, 1);
+  }
+  if (ns) HIPCHK(hipMemcpyAsync(h_stage, sbuf, sizeof(double) * ns, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (cb_alltoallv(cb_ctx, h_stage, soffs.data(), h_stage2, roffs.data(), rank, world) != 0) {
+    err = "alltoallv callback failed";
+    return SIM3OPT_ERR_COMM;
+  }
+  if (nr) HIPCHK(hipMemcpyAsync(rbuf, h_stage2, sizeof(double) * nr, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  return SIM3OPT_OK;
 }
 
 int Comm::allreduce_impl(double* dptr, int n, int op, hipStream_t stream, std::string& err) {
@@ -242,6 +305,10 @@ void Comm::release() {
   if (h_stage) (void)hipHostFree(h_stage);
   h_stage = nullptr;
   h_stage_len = 0;
+  if (h_stage2) (void)hipHostFree(h_stage2);
+  h_stage2 = nullptr;
+  h_stage2_len = 0;
+  cb_alltoallv = nullptr;
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
   ev.clear();
   ev_kind.clear();

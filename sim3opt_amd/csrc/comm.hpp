@@ -24,9 +24,12 @@ struct Comm {
   void* nccl = nullptr;  // ncclComm_t
   sim3opt_allreduce_fn cb_allreduce = nullptr;
   sim3opt_allgatherv_fn cb_allgatherv = nullptr;
+  sim3opt_alltoallv_fn cb_alltoallv = nullptr;  // optional: neighbour exchange
   void* cb_ctx = nullptr;
   double* h_stage = nullptr;  // pinned staging buffer (callbacks transport)
   size_t h_stage_len = 0;
+  double* h_stage2 = nullptr;  // ... and the receive side of an exchange
+  size_t h_stage2_len = 0;
 
   bool force = false;  // run the collectives even with one rank (transport self-test)
   bool active() const { return world > 1 || force; }
@@ -36,7 +39,7 @@ struct Comm {
   bool timing = false;
   sim3opt_comm_times times{};
   std::vector<hipEvent_t> ev;     // pool, pairs
-  std::vector<int> ev_kind;       // per pair: 0 all-reduce, 1 all-gather
+  std::vector<int> ev_kind;       // per pair: 0 all-reduce, 1 all-gather, 2 neighbour exchange
   size_t ev_used = 0;
   int drain(std::string& err);
   // in-place on device memory, ordered on `stream`; op: 0 = sum, 1 = max
@@ -46,9 +49,17 @@ struct Comm {
   // hold world * count doubles: the RCCL transport then issues a single ncclAllGather
   int allgatherv(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream,
                  std::string& err);
+  // neighbour exchange: sbuf[soffs[p] .. soffs[p+1]) goes to rank p, rbuf[roffs[p] .. roffs[p+1]) comes from
+  // rank p (doubles; both plans come from the same symmetric pattern, so the two sides agree on every
+  // count).  RCCL: one group of ncclSend / ncclRecv pairs; callbacks: the optional alltoallv callback.
+  bool can_exchange() const { return kind == 1 || (kind == 2 && cb_alltoallv != nullptr); }
+  int exchange(const double* sbuf, const std::vector<int64_t>& soffs, double* rbuf,
+               const std::vector<int64_t>& roffs, hipStream_t stream, std::string& err);
   void release();
 
  private:
+  int exchange_impl(const double* sbuf, const std::vector<int64_t>& soffs, double* rbuf,
+                    const std::vector<int64_t>& roffs, hipStream_t stream, std::string& err);
   int allreduce_impl(double* dptr, int n, int op, hipStream_t stream, std::string& err);
   int allgatherv_impl(double* dvec, const std::vector<int64_t>& offs, hipStream_t stream, std::string& err);
   int stamp(int kind_, bool begin, hipStream_t stream, std::string& err);

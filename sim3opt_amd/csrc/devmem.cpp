@@ -18,6 +18,10 @@ struct Cache {
   std::mutex mu;
   std::map<int, std::vector<hipStream_t>> streams;                 // idle, per device
   std::map<int, std::vector<hipEvent_t>> events;
+  // the device a handle was created on: it is filed under THAT device when it comes back, whatever the
+  // calling thread's current device is then (an engine may be destroyed under another current device)
+  std::unordered_map<hipStream_t, int> stream_dev;
+  std::unordered_map<hipEvent_t, int> event_dev;
   std::map<std::pair<int, size_t>, std::vector<void*>> host_free;  // pinned blocks
   std::unordered_map<void*, std::pair<int, size_t>> host_live;
   size_t host_cached = 0;
@@ -45,10 +49,10 @@ void release_locked(Cache& c) {
   c.free_blocks.clear();
   c.cached_bytes = 0;
   for (auto& kv : c.streams)
-    for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+    for (hipStream_t s : kv.second) { (void)hipStreamDestroy(s); c.stream_dev.erase(s); }
   c.streams.clear();
   for (auto& kv : c.events)
-    for (hipEvent_t e : kv.second) (void)hipEventDestroy(e);
+    for (hipEvent_t e : kv.second) { (void)hipEventDestroy(e); c.event_dev.erase(e); }
   c.events.clear();
   for (auto& kv : c.host_free)
     for (void* p : kv.second) (void)hipHostFree(p);
@@ -124,18 +128,29 @@ hipError_t stream_acquire(hipStream_t* s) {
       return hipSuccess;
     }
   }
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  const hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.stream_dev[*s] = dev;
+  }
+  return e;
 }
 
 void stream_release(hipStream_t s) {
   if (!s) return;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   Cache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  std::vector<hipStream_t>& v = c.streams[dev];
+  auto it = c.stream_dev.find(s);
+  if (it == c.stream_dev.end()) {  // not ours
+    (void)hipStreamDestroy(s);
+    return;
+  }
+  std::vector<hipStream_t>& v = c.streams[it->second];
   if (v.size() < 8) v.push_back(s);
-  else (void)hipStreamDestroy(s);
+  else {
+    (void)hipStreamDestroy(s);
+    c.stream_dev.erase(it);
+  }
 }
 
 hipError_t event_acquire(hipEvent_t* e) {
@@ -151,18 +166,29 @@ hipError_t event_acquire(hipEvent_t* e) {
       return hipSuccess;
     }
   }
-  return hipEventCreate(e);
+  const hipError_t rc = hipEventCreate(e);
+  if (rc == hipSuccess) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.event_dev[*e] = dev;
+  }
+  return rc;
 }
 
 void event_release(hipEvent_t e) {
   if (!e) return;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   Cache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  std::vector<hipEvent_t>& v = c.events[dev];
+  auto it = c.event_dev.find(e);
+  if (it == c.event_dev.end()) {  // not ours
+    (void)hipEventDestroy(e);
+    return;
+  }
+  std::vector<hipEvent_t>& v = c.events[it->second];
   if (v.size() < 4096) v.push_back(e);
-  else (void)hipEventDestroy(e);
+  else {
+    (void)hipEventDestroy(e);
+    c.event_dev.erase(it);
+  }
 }
 
 hipError_t host_malloc(void** p, size_t bytes) {

@@ -156,8 +156,16 @@ extern "C" int sim3opt_load_kitti_direct(sim3opt_graph* g, const char* dir, int3
 // vertices S_iw = (Rw2c, tw2c, 1) and those records as edges (v0 = frame 1, v1 = frame 2), every
 // residual log(C S_v0 S_v1^-1) vanishes to the file's precision -- if the Euler convention
 // (roteu2ro, kittiDetector.h:225-243), compose, inverse and the edge orientation are the reference's.
+static int load_kitti_gt_loops_body(sim3opt_graph* g, const char* dir);
 extern "C" int sim3opt_load_kitti_gt_loops(sim3opt_graph* g, const char* dir) {
   if (!g || !dir) return SIM3OPT_ERR_ARG;
+  try {  // (std::map / std::string / istringstream allocate: nothing may cross the C boundary)
+    return load_kitti_gt_loops_body(g, dir);
+  } catch (...) {
+    return SIM3OPT_ERR_IO;
+  }
+}
+static int load_kitti_gt_loops_body(sim3opt_graph* g, const char* dir) {
   const std::string d(dir);
   // ground truth: "image_id r00 r01 r02 tx r10 ... tz" rows of the keyframes (gt_kf.txt, one comment
   // line), or the full 00.txt (row number = image id, kitti_surf.cpp:1164-1190)
@@ -189,8 +197,10 @@ extern "C" int sim3opt_load_kitti_gt_loops(sim3opt_graph* g, const char* dir) {
     s.s = 1.0;
     double a[8];
     to_array(s, a);
-    frame2v[id] = (int)frame2v.size();
-    const int rc = sim3opt_add_vertex(g, (int32_t)frame2v[id], a, row == 0);
+    if (frame2v.count(id)) return SIM3OPT_ERR_IO;  // a repeated image id would orphan its first vertex
+    const int vnew = (int)frame2v.size();
+    frame2v[id] = vnew;
+    const int rc = sim3opt_add_vertex(g, (int32_t)vnew, a, row == 0);
     if (rc != SIM3OPT_OK) return rc;
     ++row;
   }

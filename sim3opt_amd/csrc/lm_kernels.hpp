@@ -5,36 +5,6 @@
 // inverses and the FP32 block copies.  Reference call sites: kitti_surf.cpp:674-675 (everything here is
 // reached from optimizer.optimize(100)); SURVEY.md 8(a) rows a5-a8.
 #pragma once
-// ------------------------------------------------------------------------------------------
-// reductions (fixed order => deterministic)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
-__device__ __forceinline__ double block_sum(double v, double* sh4) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
-}
-
-__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n, double* sh4) {
-  // (four loads in flight per thread: with thousands of partials the plain loop was a chain of
-  // load-wait-add round trips)
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * WG < n; i += 4 * WG) {
-    const double v0 = p[i], v1 = p[i + WG], v2 = p[i + 2 * WG], v3 = p[i + 3 * WG];
-    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-  }
-  for (; i < n; i += WG) a0 += p[i];
-  return block_sum((a0 + a1) + (a2 + a3), sh4);
-}
-
 __global__ __launch_bounds__(WG) void k_final_sum(const double* __restrict__ partials, int n,
                                                   double* __restrict__ out) {
   __shared__ double sh[4];
@@ -63,19 +33,6 @@ __global__ __launch_bounds__(WG) void k_final_trace_max(const double* __restrict
   }
 }
 
-// two sums in one launch (multi-GPU PCG: [w.z, r.z] land in adjacent doubles for one all-reduce)
-__global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa,
-                                                   const double* __restrict__ pb, int n,
-                                                   double* __restrict__ out2) {
-  __shared__ double sh[4];
-  const double a = sum_partials(pa, n, sh);
-  const double b = sum_partials(pb, n, sh);
-  if (threadIdx.x == 0) {
-    out2[0] = a;
-    out2[1] = b;
-  }
-}
-
 // chi2 and the step's scale delta^T (lambda delta + b) of an LM trial: two partial arrays of different lengths,
 // each summed exactly as k_final_sum sums it, in one launch (outa and outb are adjacent in DevScalars)
 // With a pinned host mirror the three scalars the host decides a trial on (chi2, scale, the exact solve's
@@ -101,22 +58,9 @@ __global__ __launch_bounds__(WG) void k_final_sum_two(const double* __restrict__
   }
 }
 
-// multi-GPU: the breakdown flag is rank-local (a non-SPD block on one rank's rows); the ranks agree
-// on it through a max all-reduce of tmp_pq so that they keep taking the same branches
-__global__ void k_fail_to_double(DevScalars* sc) { sc->tmp_pq = sc->fail ? 1.0 : 0.0; }
-__global__ void k_double_to_fail(DevScalars* sc) { if (sc->tmp_pq > 0.0) sc->fail = 1; }
-
 // ------------------------------------------------------------------------------------------
 // per-edge residual kernels
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ Sim3 load_sim3(const Sim3* __restrict__ p) {
-  Sim3 s;
-  const double* d = reinterpret_cast<const double*>(p);
-  s.q[0] = d[0]; s.q[1] = d[1]; s.q[2] = d[2]; s.q[3] = d[3];
-  s.t[0] = d[4]; s.t[1] = d[5]; s.t[2] = d[6]; s.s = d[7];
-  return s;
-}
-
 __device__ __forceinline__ double quad_form(const double e[7], const double* __restrict__ Om) {
   double acc = 0.0;
 #pragma unroll
@@ -142,12 +86,6 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho, doub
   }
 }
 
-// FP32 copies of the blocks (multigrid matrix passes) are stored as interleaved PAIRS: entry e of
-// block k sits at 98 (k / 2) + 2 e + (k mod 2), so that ONE 8-byte load per lane brings the same entry
-// of two consecutive blocks -- 392 bytes per wavefront instruction, like an FP64 block, instead of 196.
-__host__ __device__ __forceinline__ size_t f32_pair_index(int64_t k, int e) {
-  return (size_t)98 * (size_t)(k >> 1) + (size_t)(2 * e) + (size_t)(k & 1);
-}
 
 struct EdgeArgs {
   int32_t e_lo, e_hi;  // edge range evaluated by this launch (rank's share in multi-GPU chi2)
@@ -406,72 +344,52 @@ __global__ __launch_bounds__(WG) void k_diag_reduce(int r0, int r1,
 }
 
 // ------------------------------------------------------------------------------------------
-// block-Jacobi preconditioner / smoother: Minv = omega (D + lambda W)^-1, one lane per block row
-// (Gauss-Jordan without pivoting; positive pivots <=> SPD block).  Level 0 of the system:
-// D = the row's diagonal block, W = I.  Coarse multigrid levels (diagH, W given): D = the undamped
-// Galerkin diagonal block, W = P^T P; the damped block is also stored back into vals.
+// update and scale (oplusImpl, push / pop, computeScale)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __restrict__ rowptr,
-                                               double* __restrict__ vals, double lambda,
-                                               double* __restrict__ Minv, DevScalars* sc,
-                                               double omega, const double* __restrict__ diagH,
-                                               const double* __restrict__ W,
-                                               float* __restrict__ vals32 = nullptr) {
-  const int row = r0 + blockIdx.x * WG + threadIdx.x;
-  if (row >= r1) return;
-  double a[7][7];
-  double* blk = vals + (size_t)49 * rowptr[row];
-  const int64_t kd = rowptr[row];  // the row's diagonal block
-  const double* src = diagH ? diagH + (size_t)49 * row : blk;
+// VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
+// (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
+// fact -- it stores the solve's token there, so that nobody has to reset the flag between solves --;
+// the step is then garbage and must not be applied -- the host rejects the trial)
+// `backup` (may be null) receives the estimates as they were: g2o's push() without a copy of its own.
+__global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
+                                              const double* __restrict__ x, Sim3* states,
+                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup,
+                                              int fail_token) {
+  const int v = blockIdx.x * WG + threadIdx.x;
+  if (v >= nv) return;
+  if (backup) {
+    const double* s8 = reinterpret_cast<const double*>(states + v);
+    double* b8 = reinterpret_cast<double*>(backup + v);
 #pragma unroll
-  for (int c = 0; c < 7; ++c)
-#pragma unroll
-    for (int r = 0; r < 7; ++r) a[r][c] = src[7 * c + r];
-  if (W) {
-    const double* w = W + (size_t)49 * row;
-#pragma unroll
-    for (int c = 0; c < 7; ++c)
-#pragma unroll
-      for (int r = 0; r < 7; ++r) {
-        a[r][c] += lambda * w[7 * c + r];
-        blk[7 * c + r] = a[r][c];
-        if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
-      }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) a[i][i] += lambda;
+    for (int i = 0; i < 8; ++i) b8[i] = s8[i];
   }
-  bool spd = true;
+  if (sc && sc->fail == fail_token) return;
+  const int h = hidx[v];
+  if (h < 0) return;
+  double xi[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    if (!(a[k][k] > 0.0)) spd = false;
-    const double d = 1.0 / a[k][k];
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-      if (j != k) a[k][j] *= d;
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-      if (i != k) {
-        const double f = a[i][k];
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (j != k) a[i][j] -= f * a[k][j];
-        a[i][k] = -f * d;
-      }
-    a[k][k] = d;
-  }
-  if (!spd) sc->fail = 1;
-  double* dst = Minv + (size_t)49 * row;  // row-major
-#pragma unroll
-  for (int r = 0; r < 7; ++r)
-#pragma unroll
-    for (int c = 0; c < 7; ++c) dst[7 * r + c] = omega * a[r][c];
+  for (int i = 0; i < 7; ++i) xi[i] = x[(size_t)7 * h + i];
+  const Sim3 P = sim3::exp(xi, opts);
+  const Sim3 S = sim3::mul(P, load_sim3(states + v));
+  double* d = reinterpret_cast<double*>(states + v);
+  d[0] = S.q[0]; d[1] = S.q[1]; d[2] = S.q[2]; d[3] = S.q[3];
+  d[4] = S.t[0]; d[5] = S.t[1]; d[6] = S.t[2]; d[7] = S.s;
 }
 
-// FP32 copy of a block array (the multigrid's matrix passes read it)
-__global__ __launch_bounds__(WG) void k_to_f32(size_t n, const double* __restrict__ src,
-                                               float* __restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    dst[f32_pair_index((int64_t)(i / 49), (int)(i % 49))] = (float)src[i];
+// pop(): the estimates of a rejected trial go back (a kernel: hipMemcpyAsync costs the host 6-18 us)
+__global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restrict__ src, Sim3* __restrict__ dst) {
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if (i < 8 * nv) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
 }
 
+// computeScale: sum_j x_j (lambda x_j + b_j)
+__global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
+                                              const double* __restrict__ b, double lambda,
+                                              double* __restrict__ partials) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
+    acc += x[j] * (lambda * x[j] + b[j]);
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}

@@ -1,263 +1,93 @@
-// pcg_kernels.hpp -- device side of the linear solve (included by engine.hip, inside namespace
-// sim3opt): the software-pipelined 7x7 block-CSR SpMV with its multigrid epilogues (k_spmv_span), the
-// single-reduction PCG step, the chain-segment preconditioner, the exp-map update (oplusImpl), the
-// halo exchange of the row-partitioned path and the HBM read calibration kernels.  Stands in for
+// pcg_kernels.hpp -- device side of the linear solve, non-template part (included by engine_pcg.hip ONLY,
+// inside namespace sim3opt): the single-reduction PCG step, the block-Jacobi inverses, the chain-segment
+// preconditioner, the halo exchange of the row-partitioned path, fixed-order two-value sums and the HBM read
+// calibration kernels.  The block-CSR SpMV itself is a template: spmv_kernel.hpp.  Stands in for
 // LinearSolverEigen::solve (kitti_surf.cpp:553-554) on graphs where a factorisation is not cheap;
-// SURVEY.md 8(a) rows a9-a11.
+// SURVEY.md 8(a) row a9.
 #pragma once
 // ------------------------------------------------------------------------------------------
 // PCG kernels.  Vector kernels map 63 lanes of a wavefront onto 9 block rows x 7 so a block
 // row's 7 entries sit in one wavefront (z = Minv r by shuffles) and addresses stay contiguous.
 // ------------------------------------------------------------------------------------------
-// q = (H + lambda I) p with the partial dot products p.q and (optionally) rvec.p per workgroup --
-// the block-CSR SpMV of the PCG (LinearSolverEigen's role, kitti_surf.cpp:553-554).
-// One wavefront owns a CONTIGUOUS span of block rows (host table `wrow`, balanced by block count);
-// lane = one of the 49 entries of the current 7x7 block, so its blocks and column indices are one
-// contiguous HBM stream, software-pipelined across row boundaries:
-//   * the loads of chunk k+1 (CH blocks of 392 B + ONE shared gather of p: lane 7u+c reads
-//     p[7 col_u + c]) are in flight while chunk k is consumed; the p entries reach the (r, c) lanes
-//     through the LDS crossbar (ds_bpermute), which is otherwise idle -- with one gather per block
-//     the address unit, not HBM, was the co-bottleneck (measured);
-//   * lanes 49..63 mirror lanes 0..14: every lane issues a valid coalesced load, no exec masking;
-//   * column indices / row ends: one coalesced vector load per 64, then v_readlane / ds_bpermute;
-//   * NT: the once-read block stream bypasses the cache policy so p stays in L2 / Infinity Cache;
-//   * a row ends with a wave-uniform branch (reduce 7 columns, add lambda p, store q, dots).
-// MODE 0: q = A p (+ the dot partials; the PCG's SpMV).  The multigrid preconditioner reuses the
-// same stream for its two matrix passes per level: MODE 1: q = rvec - A p (residual),
-// MODE 2: q = p + Minv (rvec - A p) (one damped block-Jacobi step; Minv = omega D^-1, row-major).
-// MODE 3 (coarse multigrid levels): MODE 2 applied to p + xc[agg] -- the piecewise-constant
-// prolongation of the coarser level's correction is added while the input vector is gathered
-// (xc through `partials_r`, which the non-PCG modes do not use).
-// VT = float: the multigrid preconditioner's matrix passes stream an FP32 copy of the blocks (half
-// the bytes; vectors, accumulation and the smoother inverses stay FP64) -- the PCG's own SpMV
-// (MODE 0) always reads the FP64 blocks.
-#ifndef SIM3OPT_SPMV_FASTPATH
-#define SIM3OPT_SPMV_FASTPATH 1
-#endif
-constexpr bool FASTPATH = SIM3OPT_SPMV_FASTPATH != 0;
-template <int CH, bool NT, int MODE, typename VT = double>
-__global__ __launch_bounds__(WG)
-// (no occupancy floor: the FP32 smoothing pass at 88 VGPRs / 5 wavefronts per SIMD without spills runs 0.5-1 %
-// faster end to end than forced to 80 VGPRs / 6 wavefronts with 3-5 spilled registers; r3_negative_results.log)
-void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
-                                                  const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ colidx,
-                                                  const VT* __restrict__ vals,
-                                                  const double* __restrict__ p,
-                                                  double* __restrict__ q, double lambda,
-                                                  double* __restrict__ partials,
-                                                  const double* __restrict__ rvec,
-                                                  double* __restrict__ partials_r,
-                                                  DevScalars* __restrict__ sc,
-                                                  const double* __restrict__ Minv, int lam_sc,
-                                                  const int32_t* __restrict__ agg,
-                                                  double xc_scale) {
+// two sums in one launch (multi-GPU PCG: [w.z, r.z] land in adjacent doubles for one all-reduce)
+__global__ __launch_bounds__(WG) void k_final_sum2(const double* __restrict__ pa,
+                                                   const double* __restrict__ pb, int n,
+                                                   double* __restrict__ out2) {
   __shared__ double sh[4];
-  __shared__ double sh2[4];
-  __shared__ int sh_cnt;
-  if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
-    if (threadIdx.x == 0) sh_cnt = 0;
-    __syncthreads();
+  const double a = sum_partials(pa, n, sh);
+  const double b = sum_partials(pb, n, sh);
+  if (threadIdx.x == 0) {
+    out2[0] = a;
+    out2[1] = b;
   }
-  if (sc) {
-    if (sc->done) return;
-    if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
-    // the previous update was the last allowed one: later launches become no-ops
-    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-      if (sc->stop) sc->done = 1;
-      sc->n_spmv_work += 1;  // (launches are stream-ordered: one writer at a time)
-    }
+}
+
+// multi-GPU: the breakdown flag is rank-local (a non-SPD block on one rank's rows); the ranks agree
+// on it through a max all-reduce of tmp_pq so that they keep taking the same branches
+__global__ void k_fail_to_double(DevScalars* sc) { sc->tmp_pq = sc->fail ? 1.0 : 0.0; }
+__global__ void k_double_to_fail(DevScalars* sc) { if (sc->tmp_pq > 0.0) sc->fail = 1; }
+
+// ------------------------------------------------------------------------------------------
+// block-Jacobi preconditioner / smoother: Minv = omega (D + lambda W)^-1, one lane per block row
+// (Gauss-Jordan without pivoting; positive pivots <=> SPD block).  Level 0 of the system:
+// D = the row's diagonal block, W = I.  Coarse multigrid levels (diagH, W given): D = the undamped
+// Galerkin diagonal block, W = P^T P; the damped block is also stored back into vals.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __restrict__ rowptr,
+                                               double* __restrict__ vals, double lambda,
+                                               double* __restrict__ Minv, DevScalars* sc,
+                                               double omega, const double* __restrict__ diagH,
+                                               const double* __restrict__ W,
+                                               float* __restrict__ vals32 = nullptr) {
+  const int row = r0 + blockIdx.x * WG + threadIdx.x;
+  if (row >= r1) return;
+  double a[7][7];
+  double* blk = vals + (size_t)49 * rowptr[row];
+  const int64_t kd = rowptr[row];  // the row's diagonal block
+  const double* src = diagH ? diagH + (size_t)49 * row : blk;
+#pragma unroll
+  for (int c = 0; c < 7; ++c)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) a[r][c] = src[7 * c + r];
+  if (W) {
+    const double* w = W + (size_t)49 * row;
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        a[r][c] += lambda * w[7 * c + r];
+        blk[7 * c + r] = a[r][c];
+        if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a[i][i] += lambda;
   }
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  const int r = lane % 7;
-  const int l49 = lane < 49 ? lane : lane - 49;
-  const int c49 = l49 / 7;
-  constexpr int NG = (CH + 7) / 8;  // shared gathers of p per chunk: eight blocks each
-  const int gu = lane / 7 < 8 ? lane / 7 : 7, gc = lane % 7;
-  const int rA = wrow[w], rB = wrow[w + 1];
-  double pq = 0.0, pr = 0.0;
-  // per-row operands are requested when the row starts and consumed when it ends
-  double pi_n = 0.0, rv_n = 0.0, mv = 0.0;
-  // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
-  // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
-  // instruction per row; the kernel is bound by the number of those, not by their bytes)
-  auto row_begin = [&](int row, int u, const double* xg) {
-    pi_n = __shfl(xg[u / 8], 7 * (u % 8) + r);
-    if (rvec) rv_n = rvec[(size_t)7 * row + r];
-    if (MODE >= 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
-  };
-  // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
-  // (row sums are valid in lanes 0..6)
-  auto row_end = [&](int row, double acc) {
-    double y = acc;
+  bool spd = true;
 #pragma unroll
-    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-    const double pi = pi_n;
-    y += lambda * pi;
-    if (MODE == 0) {
-      if (lane < 7) {
-        q[(size_t)7 * row + lane] = y;
-        pq += pi * y;
-        if (rvec) pr += rv_n * pi;
+  for (int k = 0; k < 7; ++k) {
+    if (!(a[k][k] > 0.0)) spd = false;
+    const double d = 1.0 / a[k][k];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j != k) a[k][j] *= d;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i != k) {
+        const double f = a[i][k];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+          if (j != k) a[i][j] -= f * a[k][j];
+        a[i][k] = -f * d;
       }
-    } else {
-      const double d = rv_n - y;
-      if (MODE == 1) {
-        if (lane < 7) q[(size_t)7 * row + lane] = d;
-      } else {
-        const double pr_ = mv * __shfl(d, c49);  // Minv(r, c) d_c
-        double o = pr_;
-#pragma unroll
-        for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
-        if (lane < 7) {
-          const double zo = pi + o;
-          q[(size_t)7 * row + lane] = zo;
-          // the PCG's r.z where z is born (level 0's last pass writes z = M^-1 r and holds r): the
-          // SpMV that follows then needs no load of r -- 11 us of its 166 (measured)
-          if (MODE == 2 && partials) pr += rv_n * zo;
-        }
-      }
-    }
-  };
-  if (rA < rB) {
-    const int kbeg = rowptr[rA], kend = rowptr[rB];
-    // row ends of this span, 64 at a time, one per lane
-    int rbase = rA;
-    int rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
-    int row = rA;
-    int k1 = __builtin_amdgcn_readlane(rpv, 0);
-    // FP32 blocks come in interleaved pairs (f32_pair_index): chunks start at an even block index,
-    // a leading block of the previous span is loaded and skipped
-    constexpr bool PAIR = sizeof(VT) == 4;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int k0 = PAIR ? (kbeg & ~1) : kbeg;
-    const int pmax = (kend - 1) >> 1;
-    auto load_chunk = [&](int ks, VT* dst) {
-      if (PAIR) {
-#pragma unroll
-        for (int u = 0; u < CH; u += 2) {
-          const int pp = (ks + u) >> 1;
-          const f32x2* vp = reinterpret_cast<const f32x2*>(vals) + (size_t)49 * (pp < pmax ? pp : pmax) + l49;
-          const f32x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
-          dst[u] = (VT)t.x;
-          dst[u + 1] = (VT)t.y;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int kk = ks + u < kend ? ks + u : kend - 1;
-          const VT* vp = vals + (size_t)49 * kk + l49;
-          dst[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
-        }
-      }
-    };
-    // column indices, 64 blocks at a time, one per lane; window w covers [k0 + 64 w, +64)
-    int cbase = k0;
-    int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
-    int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
-    double acc = 0.0;
-    VT vc[CH], vn[CH];
-    double xgc[NG], xgn[NG];
-    auto gather = [&](int ks, double* xg) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int kk = ks + 8 * g + gu < kend ? ks + 8 * g + gu : kend - 1;
-        const int colu = __shfl(cv, kk - cbase);
-        xg[g] = p[(size_t)7 * colu + gc];
-        if (MODE == 3) xg[g] += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
-      }
-    };
-#pragma unroll
-    for (int g = 0; g < NG; ++g) xgn[g] = 0.0;
-    // prologue: chunk at k0
-    load_chunk(k0, vc);
-    gather(k0, xgc);
-    row_begin(row, kbeg - k0, xgc);
-    for (int k = k0; k < kend; k += CH) {
-      const int kn = k + CH;
-      if (kn < kend) {  // issue the next chunk before consuming this one
-        if (kn - cbase >= 64) {  // next chunk starts a new 64-block window (CH divides 64)
-          cbase += 64;
-          cv = cvn;
-          cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
-        }
-        load_chunk(kn, vn);
-        gather(kn, xgn);
-      }
-      // a chunk that lies inside the span and inside the current row (two in three on config 3) needs no
-      // per-block tests, and its shuffles are in flight together -- the same products in the same order
-      // (bit-identical; round 3, A/B on one box: -6.5 % on the FP64 pass, -13...16 % on the coarse levels'
-      // passes, the level-0 FP32 passes unchanged).  A third path for interior chunks WITH a row boundary
-      // (no validity tests) raised the register count and lost more than it won
-      // (profiles/r3_negative_results.log)
-      const bool interior = FASTPATH && k >= kbeg && k + CH <= kend;
-      auto next_row = [&](int u) {  // row `row` is complete; block u of this chunk starts the next one
-        row_end(row, acc);
-        acc = 0.0;
-        ++row;
-        row_begin(row, u, xgc);
-        if (row - rbase >= 64) {
-          rbase += 64;
-          rpv = rbase + 1 + lane <= rB ? rowptr[rbase + 1 + lane] : kend;
-        }
-        k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
-      };
-      if (interior && k1 >= k + CH) {
-#pragma unroll
-        for (int h = 0; h < CH; h += 4) {  // (four at a time: eight live values cost the FP32 smoothing pass its occupancy)
-          double xs[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) xs[u] = __shfl(xgc[(h + u) / 8], 7 * ((h + u) % 8) + c49);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc += (double)vc[h + u] * xs[u];
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int kk = k + u;
-          if (kk >= kbeg && kk < kend) {
-            if (kk == k1) next_row(u);
-            acc += (double)vc[u] * __shfl(xgc[u / 8], 7 * (u % 8) + c49);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < CH; ++u) vc[u] = vn[u];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) xgc[g] = xgn[g];
-    }
-    row_end(row, acc);  // last row of the span
+    a[k][k] = d;
   }
-  if (MODE == 2 && partials) {
-    // no barrier at the end of a streaming kernel: every wavefront leaves its sum in LDS and goes;
-    // the one that arrives last adds the four in index order (deterministic) and writes the partial
-    const double t = wave_sum(pr);
-    if (lane == 0) {
-      sh[threadIdx.x >> 6] = t;
-      __threadfence_block();
-      if (atomicAdd(&sh_cnt, 1) == 3) {
-        __threadfence_block();
-        partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-      }
-    }
-    return;
-  }
-  if (MODE != 0) return;
-  {  // the same barrier-free partial sums (w.z, and r.z when this pass reads r)
-    const double s = wave_sum(pq);
-    const double t = rvec ? wave_sum(pr) : 0.0;
-    if (lane == 0) {
-      sh[threadIdx.x >> 6] = s;
-      sh2[threadIdx.x >> 6] = t;
-      __threadfence_block();
-      if (atomicAdd(&sh_cnt, 1) == 3) {
-        __threadfence_block();
-        if (partials) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        if (rvec) partials_r[blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
-      }
-    }
-  }
+  if (!spd) sc->fail = 1;
+  double* dst = Minv + (size_t)49 * row;  // row-major
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[7 * r + c] = omega * a[r][c];
 }
 
 // x = 0, r = b, z = Minv b (block-Jacobi; the chain preconditioner runs separately), p = s = 0
@@ -376,7 +206,7 @@ __global__ __launch_bounds__(64) void k_chain_factor(int r0, int r1, int seg,
 // application z = M^-1 r and partial r.z: one wavefront per segment, lane = (row rr, column cc)
 // of the 7x7 factor blocks; forward pass y_i = r_i - G_i y_{i-1} (kept in LDS), backward pass
 // z_i = S_i^-1 y_i - G_{i+1}^T z_{i+1}.  Two dependent shuffles per row and direction.
-constexpr int CHAIN_SEG_MAX = 256;
+
 __global__ __launch_bounds__(WG) void k_chain_apply(int r0, int r1, int seg,
                                                     const double* __restrict__ Sinv,
                                                     const double* __restrict__ Gm,
@@ -516,46 +346,6 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// update and scale
-// ------------------------------------------------------------------------------------------
-// VertexSim3Expmap::oplusImpl: S <- exp(dx) * S for every free vertex
-// (sc != nullptr: the exact factorisation reports a non-positive pivot through sc->fail after the
-// fact -- it stores the solve's token there, so that nobody has to reset the flag between solves --;
-// the step is then garbage and must not be applied -- the host rejects the trial)
-// `backup` (may be null) receives the estimates as they were: g2o's push() without a copy of its own.
-__global__ __launch_bounds__(WG) void k_oplus(int nv, const int32_t* __restrict__ hidx,
-                                              const double* __restrict__ x, Sim3* states,
-                                              sim3::Opts opts, const DevScalars* sc, Sim3* backup,
-                                              int fail_token) {
-  const int v = blockIdx.x * WG + threadIdx.x;
-  if (v >= nv) return;
-  if (backup) {
-    const double* s8 = reinterpret_cast<const double*>(states + v);
-    double* b8 = reinterpret_cast<double*>(backup + v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b8[i] = s8[i];
-  }
-  if (sc && sc->fail == fail_token) return;
-  const int h = hidx[v];
-  if (h < 0) return;
-  double xi[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) xi[i] = x[(size_t)7 * h + i];
-  const Sim3 P = sim3::exp(xi, opts);
-  const Sim3 S = sim3::mul(P, load_sim3(states + v));
-  double* d = reinterpret_cast<double*>(states + v);
-  d[0] = S.q[0]; d[1] = S.q[1]; d[2] = S.q[2]; d[3] = S.q[3];
-  d[4] = S.t[0]; d[5] = S.t[1]; d[6] = S.t[2]; d[7] = S.s;
-}
-
-// pop(): the estimates of a rejected trial go back (a kernel: hipMemcpyAsync costs the host 6-18 us)
-__global__ __launch_bounds__(WG) void k_copy_states(int nv, const Sim3* __restrict__ src, Sim3* __restrict__ dst) {
-  const int i = blockIdx.x * WG + threadIdx.x;
-  if (i < 8 * nv) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
-}
-
-
 // Halo exchange of the row-partitioned PCG (round 3): the boundary rows of a vector (rows with a
 // neighbour on another rank, host list `brow`, grouped by owner) are packed into one buffer, that
 // buffer is all-gathered (each rank contributes its own segment), and every foreign boundary row is
@@ -571,18 +361,6 @@ __global__ __launch_bounds__(WG) void k_halo_unpack(int n, int own0, int own1, c
   const int t = blockIdx.x * WG + threadIdx.x;
   const int k = t / 7, c = t % 7;
   if (k < n && (k < own0 || k >= own1) && brow[k] >= 0) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
-}
-
-// computeScale: sum_j x_j (lambda x_j + b_j)
-__global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __restrict__ x,
-                                              const double* __restrict__ b, double lambda,
-                                              double* __restrict__ partials) {
-  __shared__ double sh[4];
-  double acc = 0.0;
-  for (int j = j0 + blockIdx.x * WG + threadIdx.x; j < j1; j += gridDim.x * WG)
-    acc += x[j] * (lambda * x[j] + b[j]);
-  const double s = block_sum(acc, sh);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // ||r||^2 and ||b||^2 over a row range (the multigrid path verifies what its stopping test claims)
@@ -640,4 +418,5 @@ __global__ __launch_bounds__(WG) void k_stream_read(const double* __restrict__ s
   }
   if (acc == 123.456) sink[0] = acc;  // keep the loads alive
 }
+
 

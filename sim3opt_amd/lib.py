@@ -12,8 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsim3opt.so")
-# (tuning scripts A/B two builds of the library in one gpurun call: SIM3OPT_LIBRARY=<other .so>)
-LIB_PATH = os.environ.get("SIM3OPT_LIBRARY", LIB_PATH)
+# (a tuning script that A/Bs two builds sets sim3opt_amd.lib.LIB_PATH before the first load(); no
+# environment variable redirects the dlopen)
 
 OK, ERR_ARG, ERR_STATE, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_NONE, KERNEL_HUBER = 0, 1
@@ -41,6 +41,23 @@ class Options(C.Structure):
         ("verbose", C.c_int32),
         ("time_kernels", C.c_int32),
         ("linear_solver", C.c_int32),
+        ("amg_cycle", C.c_int32 * 4),
+        ("amg_passes", C.c_int32 * 3),
+        ("amg_additive", C.c_int32),
+        ("amg_fp32", C.c_int32),
+        ("amg_pivot", C.c_int32),
+        ("amg_coarsest", C.c_int32),
+        ("adaptive_prec", C.c_int32),
+        ("row_order", C.c_int32),
+        ("halo_exchange", C.c_int32),
+        ("span_grid", C.c_int32),
+        ("force_collectives", C.c_int32),
+        ("amg_shard_rows", C.c_int32),
+        ("amg_virtual_ranks", C.c_int32),
+        ("pcg_batch", C.c_int32),
+        ("amg_omega", C.c_double),
+        ("amg_over", C.c_double * 2),
+        ("direct_max_pairs", C.c_int64),
     ]
 
 
@@ -56,6 +73,8 @@ class IterStats(C.Structure):
         ("ms_linearize", C.c_double),
         ("ms_solve", C.c_double),
         ("ms_update", C.c_double),
+        ("pcg_capped", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -89,6 +108,7 @@ class CommTimes(C.Structure):
     _fields_ = [
         ("ms_allreduce", C.c_double), ("n_allreduce", C.c_int64), ("bytes_allreduce", C.c_int64),
         ("ms_allgather", C.c_double), ("n_allgather", C.c_int64), ("bytes_allgather", C.c_int64),
+        ("ms_exchange", C.c_double), ("n_exchange", C.c_int64), ("bytes_exchange", C.c_int64),
     ]
 
 
@@ -132,7 +152,6 @@ SYMBOLS = {
     "sim3opt_solve": (C.c_int, [_vp, C.c_double, _dp, _ip, _dp]),
     "sim3opt_bench_spmv": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_bench_stream": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
-    "sim3opt_bench_spmv_symmetric": (C.c_int, [_vp, C.c_int32, _dp]),
     "sim3opt_preconditioner_in_use": (C.c_int, [_vp]),
     "sim3opt_amg_hierarchy": (C.c_int, [_vp, C.c_int32, _ip, _ip, _vp, _ip]),
     "sim3opt_linear_solver_in_use": (C.c_int, [_vp]),
@@ -143,6 +162,7 @@ SYMBOLS = {
     "sim3opt_comm_unique_id": (C.c_int, [_up]),
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "sim3opt_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, C.POINTER(C.c_int64)]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
@@ -181,6 +201,23 @@ SYMBOLS = {
 _lib = None
 
 
+OPTIONAL_SYMBOLS = {
+    "sim3opt_bench_spmv_symmetric": (C.c_int, [_vp, C.c_int32, _dp]),
+}
+
+
+def hip_runtime_path():
+    """Path of the libamdhip64 this process has mapped (the one libsim3opt.so is bound to), or None."""
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln:
+                    return ln.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
 def load():
     """Loads libsim3opt.so and binds every declared symbol (raises if one is missing)."""
     global _lib
@@ -191,24 +228,35 @@ def load():
         # One HIP runtime per process: libsim3opt.so names the system's libamdhip64, a PyTorch-ROCm wheel
         # carries its own.  Whichever is mapped first serves both (same soname) -- but if the library were
         # mapped before torch and torch then initialised its own copy, the library's copy would find the
-        # device taken ("no usable HIP device").  This harness lives next to torch (bench.py, tests): map
-        # torch's first where torch exists.  A C / C++ host that does not use torch is not concerned.
-        if "torch" not in sys.modules:
+        # device taken ("no usable HIP device").  So a process that will ALSO use torch (bench.py, the
+        # tests, build() + smoke() in one interpreter) must map torch's first: it says so by importing
+        # torch before this call, or by SIM3OPT_PRELOAD_TORCH=1.  Otherwise the library binds to the ROCm
+        # it was compiled against and this module imports nothing.
+        if "torch" not in sys.modules and os.environ.get("SIM3OPT_PRELOAD_TORCH", "0") not in ("", "0"):
             try:
                 import torch  # noqa: F401
             except Exception:  # no torch in this interpreter: the system runtime is the only one
                 pass
         L = C.CDLL(LIB_PATH)
+        if os.environ.get("SIM3OPT_VERBOSE_LOAD"):
+            print(f"sim3opt: {LIB_PATH} loaded; HIP runtime mapped: {hip_runtime_path()}", file=sys.stderr)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in OPTIONAL_SYMBOLS.items():  # a SIM3OPT_BENCH_HOOKS build only
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int32, C.c_int32)
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int64), C.c_int32,
+                           C.c_int32)
 
 
 class Sim3OptError(RuntimeError):
@@ -329,9 +377,11 @@ class Graph:
         assert uid.shape == (128,)
         self._chk(self._L.sim3opt_comm_init(self._g, int(rank), int(world), _p(uid, _up)))
 
-    def comm_init_callbacks(self, rank, world, allreduce, allgatherv):
+    def comm_init_callbacks(self, rank, world, allreduce, allgatherv, alltoallv=None):
         """allreduce(np_array, op) and allgatherv(np_array, offsets, rank) operate IN PLACE on
-        numpy views of the library's pinned host staging buffer."""
+        numpy views of the library's pinned host staging buffer; the optional
+        alltoallv(send, send_offsets, recv, recv_offsets, rank) is the neighbour exchange
+        (send[send_offsets[p]:send_offsets[p+1]] goes to rank p, recv[...] comes from it)."""
         def _ar(ctx, buf, n, op):
             try:
                 allreduce(np.ctypeslib.as_array(buf, shape=(n,)), int(op))
@@ -351,10 +401,25 @@ class Graph:
                 traceback.print_exc()
                 return 1
 
-        self._cb_refs = (ALLREDUCE_FN(_ar), ALLGATHERV_FN(_ag))  # keep alive
+        def _aa(ctx, sbuf, soffs, rbuf, roffs, rk, world_):
+            try:
+                so = np.ctypeslib.as_array(soffs, shape=(world_ + 1,))
+                ro = np.ctypeslib.as_array(roffs, shape=(world_ + 1,))
+                sv = np.ctypeslib.as_array(sbuf, shape=(max(int(so[-1]), 1),))
+                rv = np.ctypeslib.as_array(rbuf, shape=(max(int(ro[-1]), 1),))
+                alltoallv(sv, so, rv, ro, int(rk))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb_refs = (ALLREDUCE_FN(_ar), ALLGATHERV_FN(_ag), ALLTOALLV_FN(_aa))  # keep alive
         self._chk(self._L.sim3opt_comm_init_callbacks(
             self._g, int(rank), int(world), C.cast(self._cb_refs[0], C.c_void_p),
             C.cast(self._cb_refs[1], C.c_void_p), None))
+        if alltoallv is not None:
+            self._chk(self._L.sim3opt_comm_set_alltoallv(self._g, C.cast(self._cb_refs[2], C.c_void_p)))
 
     def local_rows(self):
         a, b = C.c_int32(), C.c_int32()

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# this harness uses torch next to the library in one process (gpu_available, torch.distributed): torch's
+# HIP runtime must be the one that is mapped first (sim3opt_amd.lib.load)
+os.environ.setdefault("SIM3OPT_PRELOAD_TORCH", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -74,6 +74,12 @@ def allgatherv(arr, offs, rank):
             dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r)
 
 
+def attach(G, rank, world):
+    """Host-staged collectives over the default gloo group for graph handle G (one place for every
+    multi-process test, so that a new callback is added once)."""
+    G.comm_init_callbacks(rank, world, allreduce, allgatherv)
+
+
 def init(rank, world, port):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
                             world_size=world)

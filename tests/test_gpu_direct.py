@@ -318,3 +318,60 @@ def test_kitti_incremental_closures_reference_arithmetic():
         assert G.stats()[-1].trials == tr[-1].trials
     assert gi == ci == [100, 1, 1, 1]
     assert synth.rmse(G.get_vertices(), states) < 1e-3
+
+
+@pytest.mark.parametrize("fixb", [0, 1])
+def test_kitti_incremental_all_118_closures_lockstep(fixb):
+    """BASELINE.json configs[4] in its own words, WHOLE: all 118 closures of loopConstraints.txt added one
+    at a time, optimize(100) after each (kitti_surf.cpp:1028-1047 is the warm start being matched), in the
+    reference's arithmetic (fixb = 0: B as written) and in the exact one.  Lock-step: every closure starts
+    both sides from the ORACLE's previous solution, so each of the 118 runs is compared on its own -- a
+    free run of 118 x 100 chaotic iterations drifts apart after the eleventh closure (DESIGN.md 2;
+    scripts/gpu_incremental.py runs it free).  Asserted per closure: LM iteration count, trials of the
+    last iteration, final chi2."""
+    full = K.build_direct_graph(False)
+    nl = 118
+    G = L.Graph(fix_small_angle_b=fixb)
+    G.add_vertices(full["states"], full["fixed"])
+    G.add_edges(full["v0"][nl:], full["v1"][nl:], full["meas"][nl:])
+    o = O.default_options(fix_small_angle_b=fixb)
+    states = full["states"].copy()
+    rec = []
+    for k in range(nl):
+        G.add_edge(int(full["v0"][k]), int(full["v1"][k]), full["meas"][k])
+        G.initialize()
+        G.set_vertices(states)
+        assert G.linear_solver_in_use() == 1
+        n = G.optimize(100)
+        st = G.stats()
+        idx = np.r_[np.arange(nl, len(full["v0"])), np.arange(k + 1)]
+        OG = O.Graph(states, full["fixed"], full["v0"][idx], full["v1"][idx], full["meas"][idx])
+        it, tr = OG.optimize(100, o)
+        rec.append((n, it, st[-1].trials, tr[-1].trials, st[-1].chi2_after, tr[-1].chi2_after,
+                    synth.rmse(G.get_vertices(), OG.states)))
+        states = OG.states.copy()
+    rec = np.array(rec)
+    same_it = int((rec[:, 0] == rec[:, 1]).sum())
+    same_tr = int((rec[:, 2] == rec[:, 3]).sum())
+    rel = np.abs(rec[:, 4] - rec[:, 5]) / np.maximum(rec[:, 5], 1e-12)
+    print(f"fix_small_angle_b={fixb}: closures with equal LM iteration count {same_it}/118, equal last-iteration "
+          f"trials {same_tr}/118, LM iterations GPU/oracle {int(rec[:, 0].sum())}/{int(rec[:, 1].sum())}, "
+          f"chi2 rel. diff median {np.median(rel):.1e} max {rel.max():.1e}, RMSE GPU vs oracle per closure "
+          f"median {np.median(rec[:, 6]):.1e} max {rec[:, 6].max():.1e}, unequal at {np.nonzero(rec[:, 0] != rec[:, 1])[0].tolist()}")
+    bounds = INCREMENTAL_BOUNDS[fixb]
+    assert same_it >= bounds["same_it"] and same_tr >= bounds["same_tr"]
+    assert np.median(rel) < bounds["chi_med"] and rel.max() < bounds["chi_max"]
+    assert np.median(rec[:, 6]) < bounds["rmse_med"]
+
+
+# per arithmetic: what one MI355X run measured (profiles/r4_incremental_lockstep.log), bounds ~3x of it
+# measured: reference arithmetic -- 112 / 118 closures with the oracle's LM iteration count (most end after ONE
+# iteration of ten rejected trials, DESIGN.md 2), 107 with its last-iteration trial count, chi2 relative
+# difference median 1.5e-16 (max 7.5e-2 where a 100-iteration episode starts on one side only), RMSE median 0;
+# exact B -- every closure converges, the Terminate iteration of a converged run is decided at the noise floor
+# of the delta = 1e-9 Jacobians (equal in 15 closures; 5684 against 5582 LM iterations in all), chi2 relative
+# difference median 2.3e-6 (max 1.3e-3), RMSE per closure median 5e-3 m
+INCREMENTAL_BOUNDS = {
+    0: dict(same_it=105, same_tr=98, chi_med=1e-12, chi_max=0.25, rmse_med=1e-9),
+    1: dict(same_it=6, same_tr=8, chi_med=1e-5, chi_max=5e-3, rmse_med=2e-2),
+}

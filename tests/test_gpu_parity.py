@@ -664,22 +664,6 @@ def test_config2_chain_loop_full_size_properties():
     assert all(s.chi2_after <= s.chi2_before for s in st)
 
 
-def test_symmetric_spmv_prototype_matches_product_spmv():
-    """csrc/symm_proto.hpp (measurement prototype of the two-phase upper-triangle SpMV):
-    same result as the product SpMV on a graph with parallel edges and a fixed vertex."""
-    synth.DRIFT_TARGET = 0.05
-    g = synth.manhattan(2000, 18000, dims=(14, 14, 10))
-    v0 = np.concatenate([g["v0"], g["v0"][:50]])  # parallel edges: repeated columns in a row
-    v1 = np.concatenate([g["v1"], g["v1"][:50]])
-    meas = np.concatenate([g["meas"], g["meas"][:50]])
-    G = mk(dict(g, v0=v0, v1=v1, meas=meas), fix_small_angle_b=1, preconditioner=0)
-    G.linearize()
-    p1, p2, err, byt = G.bench_spmv_symmetric(2)
-    nb, nnzb = G.system_dims()
-    assert err < 1e-13 and p1 > 0 and p2 > 0
-    assert byt < 0.72 * (nnzb * 396.0)  # (nb + (nnzb - nb) / 2 blocks + 112 B of t per off-diagonal block)
-
-
 def test_config3_manhattan_full_size_properties():
     """100k vertices / 1M edges (BASELINE.json config 3): properties only."""
     synth.DRIFT_TARGET = 0.05
