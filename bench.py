@@ -135,6 +135,18 @@ def cpu_baseline(args, g, gpu_ms_linearize, gpu_value, threads=1):
     }
 
 
+def solver_options(G):
+    o = G.options()
+    names = ("amg_cycle", "amg_passes", "amg_additive", "amg_fp32", "amg_pivot", "amg_coarsest", "adaptive_prec",
+             "row_order", "halo_exchange", "span_grid", "amg_shard_rows", "amg_virtual_ranks", "pcg_batch",
+             "amg_omega", "amg_over", "pcg_check_every", "pcg_graph", "pcg_max_iters")
+    out = {}
+    for n in names:
+        v = getattr(o, n)
+        out[n] = list(v) if hasattr(v, "__len__") else v
+    return out
+
+
 def optimize100_leg(args, g, device):
     """The reference's own call on the benchmark graph: initializeOptimization(); optimize(100)
     (kitti_surf.cpp:674-675) from the initial state until g2o's Terminate rule (ten rejected trials,
@@ -322,6 +334,15 @@ def main():
                 if offs[r + 1] > offs[r]:
                     dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r, group=gloo_group)
 
+        def _aa(send, soffs, recv, roffs, rk):
+            ts, tr = torch.from_numpy(send), torch.from_numpy(recv)
+            reqs = [dist.irecv(tr[int(roffs[p]):int(roffs[p + 1])], src=p, group=gloo_group)
+                    for p in range(len(roffs) - 1) if roffs[p + 1] > roffs[p]]
+            reqs += [dist.isend(ts[int(soffs[p]):int(soffs[p + 1])].clone(), dst=p, group=gloo_group)
+                     for p in range(len(soffs) - 1) if soffs[p + 1] > soffs[p]]
+            for q in reqs:
+                q.wait()
+
         ok = 0
         if args.transport == "rccl":
             # the library builds its own RCCL communicator from an id broadcast over torch's group
@@ -345,7 +366,7 @@ def main():
             # library's RCCL communicator not come up on some rank (same partitioned kernels)
             if args.transport != "gloo":
                 gloo_group = dist.new_group(backend="gloo")
-            G.comm_init_callbacks(rank, world, _ar, _ag)
+            G.comm_init_callbacks(rank, world, _ar, _ag, _aa)
             transport_used = "gloo"
     G.initialize()  # uploads everything to HBM
     chi2_0 = G.chi2()
@@ -450,7 +471,11 @@ def main():
                                      if args.fix_small_angle_b else "reference (B as written)",
                        "preconditioner": prec_name,
                        "parallelism": "single GPU" if world == 1 else f"row-partition x{world}",
-                       "transport": transport_used},
+                       "transport": transport_used,
+                       # the tuning options the run used (sim3opt_get_options after initialize: environment
+                       # overrides included) and the SIM3OPT_* variables that were set
+                       "solver_options": solver_options(G),
+                       "env_overrides": {k: v for k, v in os.environ.items() if k.startswith("SIM3OPT_")}},
             "edges_iters_per_s": args.edges * K / dt,
             "chi2_initial": chi2_0, "chi2_final": chi2_final,
             "lm_trials": [int(s.trials) for s in stats],
@@ -458,6 +483,8 @@ def main():
             "pcg_rel_res": [float("%.2e" % s.pcg_rel_res) for s in stats],
             # solves that stopped at the iteration cap short of the tolerance (an inexact LM step; 0 here)
             "unconverged_solves": int(sum(int(s.pcg_capped) for s in stats)),
+            # device time of every LM iteration's solves (all its trials): the bursts of rejected trials show here
+            "ms_solve": [float("%.2f" % s.ms_solve) for s in stats],
             "ms_linearize_mean": float(np.mean([s.ms_linearize for s in stats])),
             "ms_solve_mean": float(np.mean([s.ms_solve for s in stats])),
             "ms_update_mean": float(np.mean([s.ms_update for s in stats])),
@@ -467,12 +494,16 @@ def main():
             # rank 0's collectives inside the timed region: device time (includes waiting for the
             # slowest rank), count, payload -- what the next scaling decision needs
             npcg = max(sum(int(s.pcg_iters) for s in stats), 1)
-            out["collectives_rank0"] = dict(ct, ms_per_lm_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / K,
-                                            ms_per_pcg_iteration=(ct["ms_allreduce"] + ct["ms_allgather"]) / npcg,
-                                            fraction_of_step=(ct["ms_allreduce"] + ct["ms_allgather"]) / (dt * 1e3),
-                                            # payload of the buffers exchanged (whole buffer; a rank receives
-                                            # (N - 1) / N of an all-gather), per PCG iteration
-                                            bytes_per_pcg_iteration=(ct["bytes_allreduce"] + ct["bytes_allgather"]) / npcg)
+            ms_all = ct["ms_allreduce"] + ct["ms_allgather"] + ct["ms_exchange"]
+            n_all = ct["n_allreduce"] + ct["n_allgather"] + ct["n_exchange"]
+            by_all = ct["bytes_allreduce"] + ct["bytes_allgather"] + ct["bytes_exchange"]
+            out["collectives_rank0"] = dict(ct, ms_per_lm_iteration=ms_all / K, ms_per_pcg_iteration=ms_all / npcg,
+                                            fraction_of_step=ms_all / (dt * 1e3),
+                                            collectives_per_pcg_iteration=n_all / npcg,
+                                            # payload: whole buffer of an all-reduce / all-gather (a rank receives
+                                            # (N - 1) / N of an all-gather); sent + received bytes of this rank
+                                            # for the neighbour exchanges; per PCG iteration
+                                            bytes_per_pcg_iteration=by_all / npcg)
             # the partition the collectives serve: rows in breadth-first locality order, equal spans
             _, _, bnd, cut = G.partition_plan(world)
             out["partition"] = {"row_order": "breadth-first locality order", "rows": int(nb),

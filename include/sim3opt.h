@@ -159,6 +159,12 @@ typedef struct sim3opt_kernel_times {
   double ms_linearize; int64_t n_linearize;
   double ms_chi2;      int64_t n_chi2;
   double ms_update;    int64_t n_update;
+  /* multigrid cycles: device time spent on the levels a rank partition REPLICATES (every rank runs them whole:
+   * the part of a PCG iteration that does not shrink with the number of ranks) and the number of visits of the
+   * first such level; on one rank with options.amg_virtual_ranks = N: what an N-rank run would replicate */
+  double ms_replicated_levels; int64_t n_replicated_visits;
+  /* batched solves of rejected LM trials (options.pcg_batch): batches run, systems they held */
+  int64_t n_batches; int64_t n_batched_solves;
 } sim3opt_kernel_times;
 
 /* Device time of the collectives of the row-partitioned path accumulated since initialize / reset
@@ -337,6 +343,12 @@ int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t 
  * *cut_edges: edges whose endpoints two ranks own (both linearise them). */
 int sim3opt_partition_plan(sim3opt_graph* g, int32_t world, int32_t locality, int32_t* vertex_of_row,
                            int32_t* row_begin, int32_t* boundary_rows_of_rank, int64_t* cut_edges);
+/* Neighbour-only exchange plan of rank `rank` on level 0 of the partition over `world` ranks (host only;
+ * locality order): rows it sends (its own rows another rank's rows reference, grouped by that rank:
+ * send_seg has world + 1 entries) and rows it receives (grouped by owner).  Two calls: rows NULL to get
+ * the counts.  By the symmetry of the pattern, rank p's receive group for q equals q's send group for p. */
+int sim3opt_halo_plan(sim3opt_graph* g, int32_t world, int32_t rank, int32_t* n_send, int32_t* n_recv,
+                      int32_t* send_rows, int32_t* send_seg, int32_t* recv_rows, int32_t* recv_seg);
 /* block-row range [begin, end) this graph's rank owns (valid after initialize) */
 int sim3opt_local_rows(const sim3opt_graph* g, int32_t* begin, int32_t* end);
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WG) void k_amg_adjoint(int nb, const int32_t* __res
 // Every fine block is read exactly once here, so the FP32 copy the cycle's matrix passes stream
 // (vals32_f, may be null) is written on the way.
 template <bool HASP>
-__global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __restrict__ gptr,
+__global__ __launch_bounds__(WG) void k_amg_galerkin(int cb0, int cb1, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ gblk,
                                                      const int32_t* __restrict__ grow,
                                                      const int32_t* __restrict__ colidx_f,
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int ncb, const int32_t* __r
                                                      double* __restrict__ vals_c,
                                                      float* __restrict__ vals32_f) {
   const int lane = threadIdx.x & 63;
-  const int cb = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (cb >= ncb) return;
+  const int cb = cb0 + __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (cb >= cb1) return;
   const int l49 = lane < 49 ? lane : lane - 49;
   const int r = l49 % 7, c = l49 / 7;
   double acc = 0.0;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WG) void k_amg_wsum(int nc, const int32_t* __restri
 // Coarse levels (piecewise-constant prolongation): r_c[a] = sum over members i of t_f[i]; then
 // x_c[a] = Minv_c[a] r_c[a] (first smoothing step of the coarser level from a zero guess).
 // 63 lanes = 9 aggregates x 7 entries.
-__global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __restrict__ mptr,
+__global__ __launch_bounds__(WG) void k_amg_restrict(int a_lo, int nc, const int32_t* __restrict__ mptr,
                                                      const int32_t* __restrict__ mem,
                                                      const double* __restrict__ t_f,
                                                      double* __restrict__ r_c,
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  for (int a0 = (blockIdx.x * 4 + wave) * 9; a0 < nc; a0 += gridDim.x * 36) {
+  for (int a0 = a_lo + (blockIdx.x * 4 + wave) * 9; a0 < nc; a0 += gridDim.x * 36) {  // aggregates [a_lo, nc)
     const int a = a0 + sub;
     const bool act = lane < 63 && a < nc;
     const int e0 = act ? mptr[a] : 0, e1 = act ? mptr[a + 1] : 0;
@@ -214,26 +214,24 @@ __global__ __launch_bounds__(WG) void k_amg_restrict(int nc, const int32_t* __re
 // Level-0 restriction, one wavefront per aggregate: lane (m, c) = entry l49 = m + 7c of P_i (one
 // coalesced 392-byte read per member), r_c[c] = sum_i sum_m P_i[m][c] t_i[m]; then the coarse
 // level's first smoothing step x_c = Minv_c r_c with Minv_c read the same way.
-__global__ __launch_bounds__(WG) void k_amg_restrict0(int nc, const int32_t* __restrict__ mptr,
+__global__ __launch_bounds__(WG) void k_amg_restrict0(int a_lo, int nc, const int32_t* __restrict__ mptr,
                                                       const int32_t* __restrict__ mem,
                                                       const double* __restrict__ P,
                                                       const double* __restrict__ t_f,
                                                       double* __restrict__ r_c,
                                                       const double* __restrict__ Minv_c,
                                                       double* __restrict__ x_c,
-                                                      const DevScalars* __restrict__ sc, int row_lo,
-                                                      int row_hi) {
+                                                      const DevScalars* __restrict__ sc) {
   if (sc && sc->done) return;
   const int lane = threadIdx.x & 63;
-  const int a = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int a = a_lo + __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));  // [a_lo, nc)
   if (a >= nc) return;
   const int l49 = lane < 49 ? lane : lane - 49;
   const int m = l49 % 7, c = l49 / 7;
   double acc = 0.0;
   const int e0 = mptr[a], e1 = mptr[a + 1];
   for (int e = e0; e < e1; ++e) {
-    const int i = mem[e];
-    if (i < row_lo || i >= row_hi) continue;  // wave-uniform (multi-GPU: members of other ranks)
+    const int i = mem[e];  // (multi-GPU: an aggregate's members all belong to the rank that owns it)
     acc += P[(size_t)49 * i + l49] * t_f[(size_t)7 * i + m];
   }
   // sum over m inside each group of 7 lanes (fixed c): lanes 7c .. 7c+6
@@ -272,8 +270,10 @@ __global__ __launch_bounds__(WG) void k_amg_bjapply(int nb, const double* __rest
 }
 
 // x_out[i] = x_in[i] + P_i x_c[agg[i]]   (x_out may be x_in)
+// rows [row_lo, row_hi), or -- with a list -- rows list[row_lo .. row_hi)
 template <bool HASP>
-__global__ __launch_bounds__(WG) void k_amg_prolong(int nb, const int32_t* __restrict__ agg,
+__global__ __launch_bounds__(WG) void k_amg_prolong(int row_lo, int row_hi, const int32_t* __restrict__ list,
+                                                    const int32_t* __restrict__ agg,
                                                     const double* __restrict__ P,
                                                     const double* __restrict__ x_c,
                                                     const double* x_in, double* x_out,
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(WG) void k_amg_prolong(int nb, const int32_t* __res
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
-  for (int row0 = (blockIdx.x * 4 + wave) * 9; row0 < nb; row0 += gridDim.x * 36) {
-    const int row = row0 + sub;
-    const bool act = lane < 63 && row < nb;
+  for (int row0 = row_lo + (blockIdx.x * 4 + wave) * 9; row0 < row_hi; row0 += gridDim.x * 36) {
+    const bool act = lane < 63 && row0 + sub < row_hi;
+    const int row = act ? (list ? list[row0 + sub] : row0 + sub) : 0;
     const double xc = act ? x_c[(size_t)7 * agg[row] + rr] : 0.0;
     double add = xc;
     if (HASP) {
@@ -305,7 +305,9 @@ constexpr int AMG_DENSE_MAX_N = 7 * AMG_MAX_COARSEST;
 __global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ colidx,
                                                        const double* __restrict__ vals,
-                                                       double* __restrict__ A) {
+                                                       double* __restrict__ A,
+                                                       const double* __restrict__ diag64 = nullptr) {
+  // diag64 (one of several systems solved together): the damped diagonal blocks of THIS system, [row][49]
   const int n = 7 * nb;
   const int nnz = 49 * rowptr[nb];
   for (int t = blockIdx.x * WG + threadIdx.x; t < nnz; t += gridDim.x * WG) {
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(WG) void k_amg_dense_fill(int nb, const int32_t* __
       const int mid = (lo + hi) >> 1;
       if (rowptr[mid] <= k) lo = mid; else hi = mid;
     }
-    A[(size_t)(7 * lo + e % 7) * n + 7 * colidx[k] + e / 7] = vals[(size_t)49 * k + e];
+    const double v = diag64 && k == rowptr[lo] ? diag64[(size_t)49 * lo + e] : vals[(size_t)49 * k + e];
+    A[(size_t)(7 * lo + e % 7) * n + 7 * colidx[k] + e / 7] = v;
   }
 }
 

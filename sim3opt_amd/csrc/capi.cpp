@@ -552,11 +552,27 @@ int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels,
                           int64_t* blocks, int32_t* aggregate_of_row) {
   try {
   if (!g || !n_levels || capacity < 0) return fail(g, SIM3OPT_ERR_ARG, "amg_hierarchy: bad argument");
+  // (the hierarchy sim3opt_initialize would build on ONE rank with the handle's options: row order,
+  // matching passes, dense-level cap and, with amg_virtual_ranks, the aggregation of an N-rank partition)
+  sim3opt_options o = g->opt;
+  apply_env_overrides(o);
   Structure st;
-  if (!build_structure(g->host, st, g->err)) return SIM3OPT_ERR_STATE;
+  std::vector<int32_t> order;
+  if (o.row_order == 1) locality_order(g->host, order);
+  if (!build_structure(g->host, st, g->err, o.row_order == 1 ? &order : nullptr)) return SIM3OPT_ERR_STATE;
   std::vector<AmgLevelHost> levels;
   std::string why;
-  if (!build_amg_hierarchy(st.nb, st.rowptr.data(), st.colidx.data(), levels, why)) {
+  AmgBuildOptions bo;
+  bo.max_coarsest = o.amg_coarsest;
+  for (int k = 0; k < 3; ++k) bo.passes[k] = o.amg_passes[k];
+  std::vector<int32_t> vbegin;
+  if (o.amg_virtual_ranks > 1) {
+    bo.world = o.amg_virtual_ranks;
+    vbegin.resize(bo.world + 1);
+    partition_rows_equal(st.nb, bo.world, vbegin.data());
+    bo.row_begin = vbegin.data();
+  }
+  if (!build_amg_hierarchy(st.nb, st.rowptr.data(), st.colidx.data(), levels, why, bo)) {
     g->err = "amg_hierarchy: " + why;
     return SIM3OPT_ERR_STATE;
   }
@@ -681,6 +697,29 @@ int sim3opt_comm_init_callbacks(sim3opt_graph* g, int32_t rank, int32_t world,
   g->comm.cb_ctx = ctx;
   g->comm_set = world > 1;
   return SIM3OPT_OK;
+}
+
+int sim3opt_halo_plan(sim3opt_graph* g, int32_t world, int32_t rank, int32_t* n_send, int32_t* n_recv,
+                      int32_t* send_rows, int32_t* send_seg, int32_t* recv_rows, int32_t* recv_seg) {
+  try {
+    if (!g || world < 1 || rank < 0 || rank >= world) return fail(g, SIM3OPT_ERR_ARG, "halo_plan: bad argument");
+    std::vector<int32_t> order;
+    locality_order(g->host, order);
+    Structure st;
+    if (!build_structure(g->host, st, g->err, &order)) return SIM3OPT_ERR_STATE;
+    std::vector<int32_t> begin(world + 1), sr, ss, rr, rs;
+    partition_rows_equal(st.nb, world, begin.data());
+    halo_plan(st.nb, st.rowptr.data(), st.colidx.data(), world, begin.data(), rank, sr, ss, rr, rs);
+    if (n_send) *n_send = (int32_t)sr.size();
+    if (n_recv) *n_recv = (int32_t)rr.size();
+    if (send_rows) std::memcpy(send_rows, sr.data(), sizeof(int32_t) * sr.size());
+    if (recv_rows) std::memcpy(recv_rows, rr.data(), sizeof(int32_t) * rr.size());
+    if (send_seg) std::memcpy(send_seg, ss.data(), sizeof(int32_t) * ss.size());
+    if (recv_seg) std::memcpy(recv_seg, rs.data(), sizeof(int32_t) * rs.size());
+    return SIM3OPT_OK;
+  } catch (...) {
+    return fail(g, SIM3OPT_ERR_ARG, "halo_plan: out of host memory or internal error");
+  }
 }
 
 int sim3opt_comm_set_alltoallv(sim3opt_graph* g, sim3opt_alltoallv_fn alltoallv) {

@@ -30,18 +30,28 @@ void Engine::release_under_device() {
   void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
                   d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
                   d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
-                  d_sub_first, d_sub_cnt, d_Gm, d_brow, d_halo, d_ptab};
+                  d_sub_first, d_sub_cnt, d_Gm, d_ptab};
   for (void* p : ptrs)
     if (p) dev_free(p);
   for (void* p : amg_owned)
     if (p) dev_free(p);
   amg_owned.clear();
+  for (LevelPart& lp : parts) {
+    void* q[] = {lp.d_send, lp.d_recv, lp.d_sbuf, lp.d_rbuf};
+    for (void* p : q)
+      if (p) dev_free(p);
+  }
+  parts.clear();
+  n_sharded = 0;
+  batch_release();
   for (void* p : direct_owned)
     if (p) dev_free(p);
   direct_owned.clear();
   staged.release();
   if (h_sc) host_free(h_sc);
   for (hipEvent_t e : pool) event_release(e);
+  for (hipEvent_t e : rep_pool) event_release(e);
+  rep_pool.clear();
   if (ev_a) event_release(ev_a);
   if (ev_b) event_release(ev_b);
   for (hipEvent_t& e : ev_ph) if (e) { event_release(e); e = nullptr; }
@@ -79,32 +89,11 @@ int Engine::init(const HostGraph& g, const Structure& s, std::string& err) {
   r1 = row_begin[comm.rank + 1];
   offs.resize(comm.world + 1);
   for (int r = 0; r <= comm.world; ++r) offs[r] = 7 * (int64_t)row_begin[r];
-  if (comm.world > 1 && opt.halo_exchange) {
-    std::vector<int32_t> brow_list;
-    boundary_rows(nb, s.rowptr.data(), s.colidx.data(), comm.world, row_begin.data(), brow_list, halo_seg);
-    n_halo = (int32_t)brow_list.size();
-    // every rank's segment of the exchange buffer has the same length (the largest boundary, short
-    // ones padded with -1): the exchange is then ONE in-place ncclAllGather, like the whole-vector one
-    halo_slots = 0;
-    for (int r = 0; r < comm.world; ++r) halo_slots = std::max(halo_slots, halo_seg[r + 1] - halo_seg[r]);
-    halo_offs.resize(comm.world + 1);
-    for (int r = 0; r <= comm.world; ++r) halo_offs[r] = 7 * (int64_t)halo_slots * r;
-    // (worth it while the boundary is a fraction of the vector; a partition in insertion order of a
-    // graph without locality has nearly every row on it: the plain all-gather is cheaper then)
-    use_halo = n_halo > 0 && (int64_t)halo_slots * comm.world * 2 < nb;
-    if (use_halo) {
-      std::vector<int32_t> padded((size_t)halo_slots * comm.world, -1);
-      for (int r = 0; r < comm.world; ++r)
-        std::copy(brow_list.begin() + halo_seg[r], brow_list.begin() + halo_seg[r + 1],
-                  padded.begin() + (size_t)halo_slots * r);
-      HIPCHK(upload(staged, stream, d_brow, padded));
-      HIPCHK(dev_malloc((void**)&d_halo, sizeof(double) * 7 * padded.size()));
-      HIPCHK(hipMemset(d_halo, 0, sizeof(double) * 7 * padded.size()));
-    }
-    if (opt.verbose)
-      std::fprintf(stderr, "sim3opt: rank %d of %d: rows [%d, %d) of %d, %d boundary rows in all (%.1f %%): %s\n",
-                   comm.rank, comm.world, r0, r1, nb, n_halo, 100.0 * n_halo / std::max(1, nb),
-                   use_halo ? "halo exchange" : "whole-vector all-gather");
+  if (comm.active()) {
+    parts.assign(1, LevelPart());
+    n_sharded = 1;
+    int rc = level_part_init(0, nb, s.rowptr.data(), s.colidx.data(), row_begin, err);
+    if (rc) return rc;
   }
   e_lo = (int32_t)((int64_t)ne * comm.rank / comm.world);
   e_hi = (int32_t)((int64_t)ne * (comm.rank + 1) / comm.world);
@@ -298,6 +287,13 @@ int Engine::pool_drain(std::string& err) {
     kt.ms_spmv += ms;
   }
   pool_used = 0;
+  for (size_t i = 0; i + 1 < rep_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, rep_pool[i], rep_pool[i + 1]));
+    kt.ms_replicated_levels += ms;
+    kt.n_replicated_visits += 1;
+  }
+  rep_used = 0;
   return SIM3OPT_OK;
 }
 
@@ -411,6 +407,8 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
     }
     double rho = 0.0;
     int qmax = 0;
+    // solutions of the next trials, solved together after a rejection (engine_batch.hip)
+    struct { int n = 0, next = 0; double lam[KB]; int32_t iters[KB]; double rel[KB]; bool capped[KB]; } batch;
     auto elapsed = [&](int a, int b, double& acc) -> int {
       if (!phase_timing) return SIM3OPT_OK;
       float ms = 0.f;
@@ -423,8 +421,49 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
       int32_t pit = 0;
       double rres = 0.0;
       bool ok2 = true;
-      rc = pcg(lambda, &pit, &rres, &ok2, err);
-      if (rc) return rc;
+      const double* xsol = d_x;  // the step of this trial
+      bool from_batch = false;
+      if (batch.next < batch.n && batch.lam[batch.next] == lambda) {
+        from_batch = true;
+      } else {
+        batch.n = batch.next = 0;
+        // A rejection has just happened: g2o's rule fixes the dampings of the next trials (lambda *= nu, nu *= 2
+        // per rejection), so the systems of the trials that may follow are solved TOGETHER -- one pass over the
+        // blocks for all of them -- and evaluated one after the other exactly as before; a trial that is
+        // accepted leaves the rest unused.  Only systems the hierarchy would solve anyway: a damping-dominated
+        // one (lambda >= the block-Jacobi gate, adaptive_prec) is cheaper on its own.
+        const int cap = qmax >= 1 ? std::min(batch_capacity(), opt.max_trials - qmax) : 0;
+        if (cap >= 2) {
+          double gate = DBL_MAX;
+          if (adaptive_prec && !trace_stale && mean_diag > 0.0) gate = bj_gate >= 0.0 ? bj_gate : 0.05 * mean_diag;
+          int nsys = 0;
+          double l = lambda, nu = ni;
+          while (nsys < cap && l < gate && std::isfinite(l)) {
+            batch.lam[nsys++] = l;
+            l *= nu;
+            nu *= 2.0;
+          }
+          if (nsys >= 2) {
+            bool usable = false;
+            rc = pcg_batch(batch.lam, nsys, batch.iters, batch.rel, batch.capped, &usable, err);
+            if (rc) return rc;
+            if (usable) {
+              batch.n = nsys;
+              from_batch = true;
+            }
+          }
+        }
+      }
+      if (from_batch) {
+        const int s = batch.next++;
+        xsol = b_x + (size_t)s * b_vs;
+        pit = batch.iters[s];
+        rres = batch.rel[s];
+        last_capped = batch.capped[s];
+      } else {
+        rc = pcg(lambda, &pit, &rres, &ok2, err);
+        if (rc) return rc;
+      }
       if (phase_timing) HIPCHK(hipEventRecord(ev_ph[2], stream));
       T.pcg_iters += pit;
       T.pcg_rel_res = rres;
@@ -434,10 +473,10 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
       double scale = 0.0;
       if (ok2) {
         hipLaunchKernelGGL(k_oplus, dim3((nv + WG - 1) / WG), dim3(WG), 0, stream, nv, d_hidx,
-                           d_x, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr, d_backup,
+                           xsol, d_states, mopts(), use_direct ? (const DevScalars*)d_sc : nullptr, d_backup,
                            fail_token);
         const int ge = grid_for(7 * (int64_t)(r1 - r0), WG);
-        hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, d_x, d_b,
+        hipLaunchKernelGGL(k_scale, dim3(ge), dim3(WG), 0, stream, 7 * r0, 7 * r1, xsol, d_b,
                            lambda, d_part_b);
         HIPCHK(hipGetLastError());
         rc = chi2(&tempChi, err, phase_timing ? ev_ph[3] : nullptr, ge);  // also sums and brings back scale (and the factorisation's verdict)

@@ -65,6 +65,7 @@ using sim3::Sim3;
 #define SIM3OPT_F32_CH 8        // blocks per pipeline step of the level-0 FP32 passes (tuning: 16)
 #endif
 constexpr int WG = 256;         // 4 wavefronts of 64
+constexpr int KB = 4;            // right-hand sides the batched PCG solves together (engine_batch.hip)
 constexpr int CHAIN_SEG_MAX = 256;  // rows per segment of the chain preconditioner (LDS of k_chain_apply)
 constexpr int PCG_GRAPH_ITERS = 16;  // PCG iterations per captured hipGraph (even: parity returns)
 constexpr int MAX_GRID = 2048;  // grid cap of the streaming kernels = number of reduction partials
@@ -149,7 +150,12 @@ class Engine {
     float* vals32 = nullptr;  // FP32 copy of vals for the cycle's matrix passes (amg_fp32)
     int32_t *agg = nullptr, *mptr = nullptr, *mem = nullptr, *gptr = nullptr, *gblk = nullptr, *grow = nullptr;
     double *r = nullptr, *x = nullptr, *t = nullptr;  // level right-hand side, iterate, residual / result
+    int32_t lo = 0, hi = 0;          // rows this rank's kernels work on: its own (partitioned level) or all
+    int32_t own_lo = 0, own_hi = 0;  // rows whose Galerkin blocks / restricted residual this rank forms from the
+    int64_t own_b0 = 0, own_b1 = 0;  //   level above (aggregates of its own rows there, or all) and their blocks
   };
+  // spans (per rank) of a level's vectors / block values: set where a partitioned level meets a replicated one
+  std::vector<std::vector<int64_t>> lvl_offs, lvl_blk_offs;
   std::vector<AmgLevel> amg;
   std::vector<void*> amg_owned;
   double *d_P = nullptr, *d_Ainv = nullptr, *d_Ainv2 = nullptr, *d_piv = nullptr, *d_az = nullptr;
@@ -182,6 +188,33 @@ class Engine {
   double mean_diag = 0.0;
   int amg_status = 0;                  // first collective error inside a cycle
   std::string amg_err;
+  // ---- several right-hand sides at once (engine_batch.hip): the rejected trials of an LM iteration ----
+  struct BatchLevel {
+    double *Minv = nullptr, *r = nullptr, *x = nullptr, *t = nullptr;  // KB systems each, strides ms / vs
+    float* diag32 = nullptr;  // coarse levels: every system's damped diagonal blocks, [row][49]
+    int64_t vs = 0, ms = 0;
+  };
+  std::vector<BatchLevel> blv;
+  std::vector<void*> batch_owned;
+  double *b_x = nullptr, *b_r = nullptr, *b_z = nullptr, *b_p = nullptr, *b_q = nullptr, *b_s = nullptr, *b_az = nullptr;
+  double *b_Ainv = nullptr, *b_diag64 = nullptr, *b_part_a = nullptr, *b_part_b = nullptr;
+  int64_t b_vs = 0, b_as = 0;
+  DevScalars *d_bsc = nullptr, *h_bsc = nullptr;
+  bool batch_ready = false;
+  int b_nsys = KB;  // systems of the batch being solved (kernels are instantiated for 2, 3, 4)
+  int batch_alloc(std::string& err);
+  void batch_release();
+  void b_spmv_mode(int level, int mode, const double* v, double* out, const double* rvec, const double* xc);
+  void b_restrict(int l, const double* t);
+  double* b_coarse(int l);
+  double* b_cycle(int l, double* cur, double* other);
+  int pcg_batch(const double* lams, int nsys, int32_t* iters, double* rel_res, bool* capped, bool* usable,
+                std::string& err);
+  // most systems a batch may hold for this graph and these options (0: no batching)
+  int batch_capacity() const {
+    if (!use_amg || use_direct || comm.active() || !amg_fp32 || amg_additive || opt.pcg_batch == 1) return 0;
+    return opt.pcg_batch > 1 ? std::min(opt.pcg_batch, KB) : KB;
+  }
   // exact sparse block Cholesky (direct.hpp, direct_kernels.hpp): LinearSolverEigen's role on
   // graphs whose factorisation is cheap (KITTI-00 and other chain-like graphs)
   DirectPlan dplan;
@@ -208,14 +241,30 @@ class Engine {
   int32_t r0 = 0, r1 = 0, e_lo = 0, e_hi = 0;
   std::vector<int32_t> row_begin;
   std::vector<int64_t> offs;
-  // halo exchange (world > 1): boundary rows of all ranks, grouped by owner; this rank's share is
-  // [halo_seg[rank], halo_seg[rank + 1]); halo_offs = 7 * halo_seg (doubles)
-  bool use_halo = false;
-  int32_t n_halo = 0, halo_slots = 0;  // boundary rows in all; slots per rank in the exchange buffer
-  std::vector<int32_t> halo_seg;
-  std::vector<int64_t> halo_offs;
-  int32_t* d_brow = nullptr;
-  double* d_halo = nullptr;
+  // Row partition of a multigrid level over the ranks (level 0 = the LM system; coarse levels with more than
+  // options.amg_shard_rows rows are partitioned too -- aggregates never straddle two ranks, so a rank's coarse
+  // rows are the aggregates of its own fine rows).  Vectors of a partitioned level are full-length on every
+  // rank; a kernel writes its own rows and reads its own rows plus the rows its blocks' columns name, which
+  // exchange_level() refreshes: neighbour-only (grouped send / receive of exactly the rows the other side
+  // reads) where the transport can, else the all-gather of the whole vector.
+  struct LevelPart {
+    int32_t lo = 0, hi = 0;               // rows of this rank
+    std::vector<int32_t> row_begin;       // world + 1
+    std::vector<int64_t> offs;            // 7 * row_begin (doubles): spans of the whole-vector all-gather
+    std::vector<int64_t> blk_offs;        // 49 * rowptr[row_begin]: spans of the level's block values
+    bool neighbour = false;               // the neighbour-only plan below is in use
+    int32_t n_send = 0, n_recv = 0;       // rows this rank sends / receives per exchange
+    int32_t *d_send = nullptr, *d_recv = nullptr;  // row lists, grouped by peer
+    std::vector<int64_t> send_offs, recv_offs;     // world + 1, doubles, into the buffers
+    double *d_sbuf = nullptr, *d_rbuf = nullptr;
+  };
+  std::vector<LevelPart> parts;  // parts[l] for l < n_sharded (world > 1 or forced collectives; else empty)
+  int n_sharded = 0;             // multigrid levels [0, n_sharded) are partitioned, the rest replicated
+  bool sharded(int l) const { return l < n_sharded; }
+  int level_part_init(int l, int32_t nb_l, const int32_t* rowptr_l, const int32_t* colidx_l,
+                      const std::vector<int32_t>& row_begin_l, std::string& err);
+  // refreshes, on level l, this rank's copy of the foreign rows its own rows read (no-op on one rank)
+  int exchange_level(int l, double* vec, std::string& err);
   // timing
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   // phase stamps of the LM loop (linearise | solve | update): recorded without waiting, read after
@@ -227,6 +276,9 @@ class Engine {
   bool phase_timing = true;
   std::vector<hipEvent_t> pool;  // pairs (start, stop) for per-launch SpMV timing
   size_t pool_used = 0;
+  std::vector<hipEvent_t> rep_pool;  // pairs around every visit of the first replicated multigrid level
+  size_t rep_used = 0;
+  int rep_level = 0;  // first multigrid level a partition over part_world() ranks replicates (0: no hierarchy)
   sim3opt_kernel_times kt{};
 
   ~Engine() { release(); }
@@ -295,7 +347,9 @@ class Engine {
 
   // Solves the level-(l+1) problem approximately (right-hand side amg[l+1].r, first iterate
   // amg[l+1].x = Minv r already there) by amg_visits[l+1] cycles; returns the buffer with the result.
-  const double* amg_coarse(int l);
+  double* amg_coarse(int l);
+  double* amg_coarse_body(int l);
+  void amg_exchange(int l, double* vec);
 
   // One multigrid cycle on level l from the iterate `cur`; `other` is scratch; returns the buffer
   // that holds the new iterate (always `other`):
@@ -337,11 +391,14 @@ class Engine {
   void direct_gather();  // once per linearisation: H in the layout of L, b permuted (k_ldl_gather)
   // block-Jacobi inverses Minv = omega (D + lambda W)^-1 of rows [lo, hi) (k_jacobi; engine_pcg.hip)
   void jacobi(int lo, int hi, const int32_t* rowptr, double* vals, double lambda, double* Minv, double omega,
-              const double* diagH, const double* W, float* vals32);
+              const double* diagH, const double* W, float* vals32, DevScalars* sc = nullptr,
+              double* diag64_out = nullptr, float* diag32_out = nullptr);
+  void norms2(const double* r, const double* b, double* part_a, double* part_b, double* out2);  // engine_pcg.hip
+  void dense_inverse(const double* diag64, double* Aout, DevScalars* sc);                         // engine_amg.hip
 
   // every rank's copy of `vec` gets the entries of the rows its own rows' blocks refer to: the boundary
   // rows only (halo exchange) where the partition has locality, the whole vector otherwise
-  int exchange_rows(double* vec, std::string& err);
+  int exchange_rows(double* vec, std::string& err) { return exchange_level(0, vec, err); }
 
   // ---- building blocks ----
   // scale_parts > 0: d_part_b holds that many partial sums of the trial's scale (k_scale): summed in the

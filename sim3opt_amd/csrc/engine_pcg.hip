@@ -8,22 +8,73 @@ namespace sim3opt {
 #include "pcg_kernels.hpp"
 
 void Engine::jacobi(int lo, int hi, const int32_t* rowptr, double* vals, double lambda, double* Minv, double omega,
-                    const double* diagH, const double* W, float* vals32) {
+                    const double* diagH, const double* W, float* vals32, DevScalars* sc, double* diag64_out,
+                    float* diag32_out) {
   hipLaunchKernelGGL(k_jacobi, dim3(std::max(1, (hi - lo + WG - 1) / WG)), dim3(WG), 0, stream, lo, hi, rowptr, vals,
-                     lambda, Minv, d_sc, omega, diagH, W, vals32);
+                     lambda, Minv, sc ? sc : d_sc, omega, diagH, W, vals32, diag64_out, diag32_out);
 }
 
-// every rank's copy of `vec` gets the entries of the rows its own rows' blocks refer to: the boundary
-// rows only (halo exchange) where the partition has locality, the whole vector otherwise
-int Engine::exchange_rows(double* vec, std::string& err) {
-  if (!use_halo) return comm.allgatherv(vec, offs, stream, err);
-  const int k0 = halo_slots * comm.rank, k1 = k0 + halo_slots, nslots = halo_slots * comm.world;
-  hipLaunchKernelGGL(k_halo_pack, dim3((7 * halo_slots + WG - 1) / WG), dim3(WG), 0, stream, k0, k1,
-                     (const int32_t*)d_brow, (const double*)vec, d_halo);
-  int rc = comm.allgatherv(d_halo, halo_offs, stream, err);
+// ||r||^2 and ||b||^2 over this rank's rows into out2[0..1] (device; fixed summation order)
+void Engine::norms2(const double* r, const double* b, double* part_a, double* part_b, double* out2) {
+  const int gn = grid_for(7 * (int64_t)(r1 - r0), WG);
+  hipLaunchKernelGGL(k_norms2, dim3(gn), dim3(WG), 0, stream, 7 * r0, 7 * r1, r, b, part_a, part_b);
+  hipLaunchKernelGGL(k_final_sum2, dim3(1), dim3(WG), 0, stream, part_a, part_b, gn, out2);
+}
+
+// Partition of level l and its exchange plan (see LevelPart).
+int Engine::level_part_init(int l, int32_t nb_l, const int32_t* rowptr_l, const int32_t* colidx_l,
+                            const std::vector<int32_t>& row_begin_l, std::string& err) {
+  LevelPart& lp = parts[l];
+  lp.row_begin = row_begin_l;
+  lp.lo = row_begin_l[comm.rank];
+  lp.hi = row_begin_l[comm.rank + 1];
+  lp.offs.resize(comm.world + 1);
+  lp.blk_offs.resize(comm.world + 1);
+  for (int r = 0; r <= comm.world; ++r) {
+    lp.offs[r] = 7 * (int64_t)row_begin_l[r];
+    lp.blk_offs[r] = 49 * (int64_t)rowptr_l[row_begin_l[r]];
+  }
+  if (comm.world <= 1 || !opt.halo_exchange || !comm.can_exchange()) return SIM3OPT_OK;
+  std::vector<int32_t> srows, sseg, rrows, rseg;
+  halo_plan(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), comm.rank, srows, sseg, rrows, rseg);
+  lp.n_send = (int32_t)srows.size();
+  lp.n_recv = (int32_t)rrows.size();
+  // (a partition without locality -- insertion order of a graph that wanders -- has nearly every row on its
+  // boundary, towards nearly every rank: the plain all-gather is cheaper then)
+  lp.neighbour = (int64_t)lp.n_send + lp.n_recv < (int64_t)nb_l;
+  if (opt.verbose)
+    std::fprintf(stderr, "sim3opt: rank %d of %d, level %d: rows [%d, %d) of %d; sends %d rows, receives %d: %s\n",
+                 comm.rank, comm.world, l, lp.lo, lp.hi, nb_l, lp.n_send, lp.n_recv,
+                 lp.neighbour ? "neighbour exchange" : "whole-vector all-gather");
+  if (!lp.neighbour) return SIM3OPT_OK;
+  lp.send_offs.resize(comm.world + 1);
+  lp.recv_offs.resize(comm.world + 1);
+  for (int r = 0; r <= comm.world; ++r) {
+    lp.send_offs[r] = 7 * (int64_t)sseg[r];
+    lp.recv_offs[r] = 7 * (int64_t)rseg[r];
+  }
+  HIPCHK(upload(staged, stream, lp.d_send, srows));
+  HIPCHK(upload(staged, stream, lp.d_recv, rrows));
+  HIPCHK(dev_malloc((void**)&lp.d_sbuf, sizeof(double) * 7 * std::max<size_t>(srows.size(), 1)));
+  HIPCHK(dev_malloc((void**)&lp.d_rbuf, sizeof(double) * 7 * std::max<size_t>(rrows.size(), 1)));
+  return SIM3OPT_OK;
+}
+
+// every rank's copy of `vec` (a vector of level l) gets the entries of the foreign rows its own rows' blocks
+// refer to: packed, sent to exactly the ranks that read them, unpacked (two ~5 us launches around the grouped
+// send / receive) -- or the all-gather of the whole vector where no neighbour plan applies
+int Engine::exchange_level(int l, double* vec, std::string& err) {
+  if (!comm.active() || l >= n_sharded) return SIM3OPT_OK;
+  LevelPart& lp = parts[l];
+  if (!lp.neighbour) return comm.allgatherv(vec, lp.offs, stream, err);
+  if (lp.n_send > 0)
+    hipLaunchKernelGGL(k_rows_gather, dim3((7 * lp.n_send + WG - 1) / WG), dim3(WG), 0, stream, lp.n_send,
+                       (const int32_t*)lp.d_send, (const double*)vec, lp.d_sbuf);
+  int rc = comm.exchange(lp.d_sbuf, lp.send_offs, lp.d_rbuf, lp.recv_offs, stream, err);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_halo_unpack, dim3((7 * nslots + WG - 1) / WG), dim3(WG), 0, stream, nslots, k0, k1,
-                     (const int32_t*)d_brow, (const double*)d_halo, vec);
+  if (lp.n_recv > 0)
+    hipLaunchKernelGGL(k_rows_scatter, dim3((7 * lp.n_recv + WG - 1) / WG), dim3(WG), 0, stream, lp.n_recv,
+                       (const int32_t*)lp.d_recv, (const double*)lp.d_rbuf, vec);
   return SIM3OPT_OK;
 }
 
@@ -345,7 +396,7 @@ int Engine::pcg_attempt(double lambda, int prec, int32_t* iters, double* rel_res
     return SIM3OPT_OK;
   }
   if (multi) {  // every rank updates its replica of all estimates
-    rc = comm.allgatherv(d_x, offs, stream, err);
+    rc = comm.allgatherv(d_x, offs, stream, err);  // (the whole step: every replica updates every estimate)
     if (rc) return rc;
     rc = agree_on_fail(err);
     if (rc) return rc;

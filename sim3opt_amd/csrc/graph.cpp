@@ -191,6 +191,37 @@ void boundary_rows(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int
   for (int32_t q = 0; q < world; ++q) seg[q + 1] += seg[q];
 }
 
+void halo_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int32_t world, const int32_t* row_begin,
+               int32_t rank, std::vector<int32_t>& send_rows, std::vector<int32_t>& send_seg,
+               std::vector<int32_t>& recv_rows, std::vector<int32_t>& recv_seg) {
+  (void)nb;
+  const int32_t lo = row_begin[rank], hi = row_begin[rank + 1];
+  auto owner_of = [&](int32_t j) {
+    return (int32_t)(std::upper_bound(row_begin, row_begin + world + 1, j) - row_begin) - 1;
+  };
+  std::vector<std::vector<int32_t>> snd(world), rcv(world);
+  for (int32_t i = lo; i < hi; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int32_t j = colidx[k];
+      if (j >= lo && j < hi) continue;
+      const int32_t p = owner_of(j);
+      if (snd[p].empty() || snd[p].back() != i) snd[p].push_back(i);  // rows ascend: duplicates are adjacent
+      rcv[p].push_back(j);
+    }
+  send_rows.clear();
+  recv_rows.clear();
+  send_seg.assign(world + 1, 0);
+  recv_seg.assign(world + 1, 0);
+  for (int32_t p = 0; p < world; ++p) {
+    std::sort(rcv[p].begin(), rcv[p].end());
+    rcv[p].erase(std::unique(rcv[p].begin(), rcv[p].end()), rcv[p].end());
+    send_rows.insert(send_rows.end(), snd[p].begin(), snd[p].end());
+    recv_rows.insert(recv_rows.end(), rcv[p].begin(), rcv[p].end());
+    send_seg[p + 1] = (int32_t)send_rows.size();
+    recv_seg[p + 1] = (int32_t)recv_rows.size();
+  }
+}
+
 void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin) {
   // split so that every rank streams about the same number of 7x7 blocks per SpMV
   const int64_t base = rowptr[0], total = (int64_t)rowptr[nb] - base;  // rowptr may be a sub-range

@@ -77,6 +77,15 @@ void locality_order(const HostGraph& g, std::vector<int32_t>& order);
 void boundary_rows(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int32_t world,
                    const int32_t* row_begin, std::vector<int32_t>& rows, std::vector<int32_t>& seg);
 
+// Neighbour-only halo plan of rank `rank` on a level with a contiguous row partition and a structurally
+// symmetric pattern: send_rows = my rows that another rank's rows reference, grouped by that rank (ascending
+// row inside a group; send_seg has world + 1 entries), recv_rows = the other ranks' rows my rows reference,
+// grouped by owner.  Built from the rank's own rows only; by the symmetry of the pattern rank p's receive
+// group for q is exactly q's send group for p, in the same order.
+void halo_plan(int32_t nb, const int32_t* rowptr, const int32_t* colidx, int32_t world, const int32_t* row_begin,
+               int32_t rank, std::vector<int32_t>& send_rows, std::vector<int32_t>& send_seg,
+               std::vector<int32_t>& recv_rows, std::vector<int32_t>& recv_seg);
+
 // Contiguous row partition balanced by stored blocks (multi-GPU row split); begin has world+1 entries.
 void partition_rows(int32_t nb, const int32_t* rowptr, int32_t world, int32_t* begin);
 

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
                                                double* __restrict__ Minv, DevScalars* sc,
                                                double omega, const double* __restrict__ diagH,
                                                const double* __restrict__ W,
-                                               float* __restrict__ vals32 = nullptr) {
+                                               float* __restrict__ vals32 = nullptr,
+                                               double* __restrict__ diag64_out = nullptr,
+                                               float* __restrict__ diag32_out = nullptr) {
   const int row = r0 + blockIdx.x * WG + threadIdx.x;
   if (row >= r1) return;
   double a[7][7];
@@ -56,8 +58,15 @@ __global__ __launch_bounds__(WG) void k_jacobi(int r0, int r1, const int32_t* __
 #pragma unroll
       for (int r = 0; r < 7; ++r) {
         a[r][c] += lambda * w[7 * c + r];
-        blk[7 * c + r] = a[r][c];
-        if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
+        if (diag64_out || diag32_out) {
+          // (one of several systems solved together, batch_kernels.hpp: the damped block goes to the system's
+          // own arrays, [row][49] column-major; the shared level arrays stay as they are)
+          if (diag64_out) diag64_out[(size_t)49 * row + 7 * c + r] = a[r][c];
+          if (diag32_out) diag32_out[(size_t)49 * row + 7 * c + r] = (float)a[r][c];
+        } else {
+          blk[7 * c + r] = a[r][c];
+          if (vals32) vals32[f32_pair_index(kd, 7 * c + r)] = (float)a[r][c];
+        }
       }
   } else {
 #pragma unroll
@@ -346,21 +355,20 @@ __global__ __launch_bounds__(WG) void k_pcg_step(int r0, int r1, int par, int it
   }
 }
 
-// Halo exchange of the row-partitioned PCG (round 3): the boundary rows of a vector (rows with a
-// neighbour on another rank, host list `brow`, grouped by owner) are packed into one buffer, that
-// buffer is all-gathered (each rank contributes its own segment), and every foreign boundary row is
-// written back into the full-length vector -- instead of all-gathering the whole vector.
-__global__ __launch_bounds__(WG) void k_halo_pack(int k0, int k1, const int32_t* __restrict__ brow,
-                                                  const double* __restrict__ vec, double* __restrict__ buf) {
-  const int t = blockIdx.x * WG + threadIdx.x;
-  const int k = k0 + t / 7, c = t % 7;
-  if (k < k1 && brow[k] >= 0) buf[(size_t)7 * k + c] = vec[(size_t)7 * brow[k] + c];
-}
-__global__ __launch_bounds__(WG) void k_halo_unpack(int n, int own0, int own1, const int32_t* __restrict__ brow,
-                                                    const double* __restrict__ buf, double* __restrict__ vec) {
+// Halo exchange of the row-partitioned path: the rows another rank reads are gathered into a send buffer
+// (host list, grouped by that rank), the buffers travel as grouped send / receive pairs, and the rows received
+// are written into the full-length vector.  Lane per entry.
+__global__ __launch_bounds__(WG) void k_rows_gather(int n, const int32_t* __restrict__ rows,
+                                                    const double* __restrict__ vec, double* __restrict__ buf) {
   const int t = blockIdx.x * WG + threadIdx.x;
   const int k = t / 7, c = t % 7;
-  if (k < n && (k < own0 || k >= own1) && brow[k] >= 0) vec[(size_t)7 * brow[k] + c] = buf[(size_t)7 * k + c];
+  if (k < n) buf[(size_t)7 * k + c] = vec[(size_t)7 * rows[k] + c];
+}
+__global__ __launch_bounds__(WG) void k_rows_scatter(int n, const int32_t* __restrict__ rows,
+                                                     const double* __restrict__ buf, double* __restrict__ vec) {
+  const int t = blockIdx.x * WG + threadIdx.x;
+  const int k = t / 7, c = t % 7;
+  if (k < n) vec[(size_t)7 * rows[k] + c] = buf[(size_t)7 * k + c];
 }
 
 // ||r||^2 and ||b||^2 over a row range (the multigrid path verifies what its stopping test claims)

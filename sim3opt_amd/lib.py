@@ -101,6 +101,8 @@ class KernelTimes(C.Structure):
         ("ms_linearize", C.c_double), ("n_linearize", C.c_int64),
         ("ms_chi2", C.c_double), ("n_chi2", C.c_int64),
         ("ms_update", C.c_double), ("n_update", C.c_int64),
+        ("ms_replicated_levels", C.c_double), ("n_replicated_visits", C.c_int64),
+        ("n_batches", C.c_int64), ("n_batched_solves", C.c_int64),
     ]
 
 
@@ -163,6 +165,7 @@ SYMBOLS = {
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sim3opt_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
+    "sim3opt_halo_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, _ip, _ip, _ip]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, C.POINTER(C.c_int64)]),
     "sim3opt_partition_rows": (C.c_int, [C.c_int32, _ip, C.c_int32, _ip]),
@@ -321,7 +324,12 @@ class Graph:
         for k, v in kw.items():
             if not hasattr(o, k):
                 raise AttributeError(k)
-            setattr(o, k, v)
+            cur = getattr(o, k)
+            if hasattr(cur, "__len__"):  # array fields (amg_cycle, amg_passes, amg_over): element by element
+                for i, x in enumerate(v):
+                    cur[i] = x
+            else:
+                setattr(o, k, v)
         self._chk(self._L.sim3opt_set_options(self._g, C.byref(o)))
 
     def options(self):
@@ -590,6 +598,17 @@ class Graph:
         self._chk(self._L.sim3opt_partition_plan(self._g, int(world), int(bool(locality)), _p(v, _ip), _p(rb, _ip),
                                                  _p(bnd, _ip), C.byref(cut)))
         return v, rb, bnd, cut.value
+
+    def halo_plan(self, world, rank):
+        """(send_rows, send_seg, recv_rows, recv_seg) of `rank` on level 0 of the `world`-rank partition; host only."""
+        ns, nr = C.c_int32(), C.c_int32()
+        self._chk(self._L.sim3opt_halo_plan(self._g, int(world), int(rank), C.byref(ns), C.byref(nr), None, None,
+                                            None, None))
+        sr, rr = np.zeros(max(ns.value, 1), np.int32), np.zeros(max(nr.value, 1), np.int32)
+        ss, rs = np.zeros(world + 1, np.int32), np.zeros(world + 1, np.int32)
+        self._chk(self._L.sim3opt_halo_plan(self._g, int(world), int(rank), None, None, _p(sr, _ip), _p(ss, _ip),
+                                            _p(rr, _ip), _p(rs, _ip)))
+        return sr[:ns.value], ss, rr[:nr.value], rs
 
     def bench_spmv(self, reps=20):
         ms = C.c_double()

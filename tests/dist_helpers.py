@@ -41,6 +41,23 @@ class ThreadGroup:
             self.bar.wait(self.timeout)
         return f
 
+    def alltoallv(self, rank):
+        def f(send, soffs, recv, roffs, rk):
+            self.slots[rank] = (send, soffs.copy())
+            self.bar.wait(self.timeout)
+            for p in range(self.world):
+                n = int(roffs[p + 1] - roffs[p])
+                if n:
+                    ps, po = self.slots[p]
+                    assert int(po[rank + 1] - po[rank]) == n  # the two plans agree on every count
+                    recv[int(roffs[p]):int(roffs[p + 1])] = ps[int(po[rank]):int(po[rank + 1])]
+            self.bar.wait(self.timeout)
+        return f
+
+    def attach(self, G, rank, neighbour=True):
+        G.comm_init_callbacks(rank, self.world, self.allreduce(rank), self.allgatherv(rank),
+                              self.alltoallv(rank) if neighbour else None)
+
     def run(self, target):
         """target(rank) -> result, one thread per rank; re-raises the first failure."""
         out, err = [None] * self.world, []
@@ -74,10 +91,25 @@ def allgatherv(arr, offs, rank):
             dist.broadcast(t[int(offs[r]):int(offs[r + 1])], src=r)
 
 
-def attach(G, rank, world):
+def alltoallv(send, soffs, recv, roffs, rank):
+    """Neighbour exchange over gloo: one isend / irecv pair per non-empty span."""
+    world = len(soffs) - 1
+    ts, tr = torch.from_numpy(send), torch.from_numpy(recv)
+    reqs = []
+    for p in range(world):
+        if roffs[p + 1] > roffs[p]:
+            reqs.append(dist.irecv(tr[int(roffs[p]):int(roffs[p + 1])], src=p))
+    for p in range(world):
+        if soffs[p + 1] > soffs[p]:
+            reqs.append(dist.isend(ts[int(soffs[p]):int(soffs[p + 1])].clone(), dst=p))
+    for r in reqs:
+        r.wait()
+
+
+def attach(G, rank, world, neighbour=True):
     """Host-staged collectives over the default gloo group for graph handle G (one place for every
     multi-process test, so that a new callback is added once)."""
-    G.comm_init_callbacks(rank, world, allreduce, allgatherv)
+    G.comm_init_callbacks(rank, world, allreduce, allgatherv, alltoallv if neighbour else None)
 
 
 def init(rank, world, port):

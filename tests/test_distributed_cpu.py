@@ -130,8 +130,10 @@ def test_partition_is_exhaustive_and_disjoint():
 
 
 # ---------------------------------------------------------------------------------------------
-# the multigrid-preconditioned PCG, row-partitioned (Engine::amg_apply, multi-GPU branch): level 0
-# partitioned, Galerkin products and restricted residuals all-reduced, coarse level replicated
+# the multigrid-preconditioned PCG, row-partitioned (Engine::amg_apply, multi-GPU branch; round 4): block rows in
+# locality order, aggregates inside the ranks' spans, so that a rank forms the Galerkin rows and the restricted
+# residual of ITS coarse rows completely -- no reduction across ranks; the replicated coarse level receives the
+# owners' pieces by all-gather; level-0 iterates travel by the neighbour exchange of the library's halo plan
 # ---------------------------------------------------------------------------------------------
 def _adjoint(S):
     """Ad(S_v) (n, 7, 7), tangent order [omega, upsilon, sigma] (amg_kernels.hpp: k_amg_adjoint)."""
@@ -152,57 +154,88 @@ def _adjoint(S):
     return Ad
 
 
-def _amg_system():
+def _amg_system(world):
     from oracle import oracle as O
     from sim3opt_amd import lib as L, synth
     synth.DRIFT_TARGET = 0.05
     g = synth.manhattan(400, 4000, dims=(6, 6, 10))
     H, b = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"]).build_dense(
         O.default_options(fix_small_angle_b=1, fd_delta=1e-6))
-    G = L.Graph()
+    # the library's own row order, partition, aggregation and halo plan (host code, no GPU)
+    G = L.Graph(row_order=1, amg_virtual_ranks=world)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
-    rows, _, agg = G.amg_hierarchy()  # the library's own aggregation (host code, no GPU)
+    rows, _, agg = G.amg_hierarchy()
     nb = rows[0]
     assert len(rows) == 2 and rows[1] <= 256
+    vor, beg, _, _ = G.partition_plan(world)          # vertex of every block row (locality order), rank spans
     free = np.where(g["fixed"] == 0)[0]
-    Ad = _adjoint(g["states"][free])
+    pos = {int(v): k for k, v in enumerate(free)}      # build_dense numbers the free vertices in insertion order
+    perm = np.array([pos[int(v)] for v in vor])
+    idx = (7 * perm[:, None] + np.arange(7)[None, :]).reshape(-1)
+    H, b = H[np.ix_(idx, idx)], b[idx]
+    Ad = _adjoint(g["states"][vor])
     P = np.zeros((7 * nb, 7 * rows[1]))
     for i in range(nb):
         P[7 * i:7 * i + 7, 7 * agg[i]:7 * agg[i] + 7] = Ad[i]
-    return H, b, P
+    # coarse rows of every rank: the aggregates of its own rows -- contiguous, and no aggregate straddles
+    cbeg = [0]
+    for r in range(world):
+        a = np.unique(agg[beg[r]:beg[r + 1]])
+        assert a.size == 0 or (a[0] == cbeg[-1] and a[-1] - a[0] + 1 == a.size)
+        cbeg.append(cbeg[-1] + a.size)
+    assert cbeg[-1] == rows[1]
+    plans = [G.halo_plan(world, r) for r in range(world)]
+    return H, b, P, np.asarray(beg), np.asarray(cbeg), plans
 
 
-def _amg_pcg(A, b, P, lam, lo, hi, offs, rank, coll):
-    """Single-reduction PCG with the two-level multiplicative cycle; rows [lo, hi) are this rank's.
-    coll = (allreduce, allgatherv) or None for a serial run (lo = 0, hi = n)."""
-    n = A.shape[0]
+def _amg_pcg(A, b, P, lam, beg, cbeg, plan, rank, coll):
+    """Single-reduction PCG with the two-level multiplicative cycle; block rows [beg[rank], beg[rank+1]) are this
+    rank's.  coll = (allreduce, allgatherv, alltoallv) or None for a serial run."""
+    n, nc = A.shape[0], P.shape[1]
     omega = 0.9
+    lo, hi = (7 * int(beg[rank]), 7 * int(beg[rank + 1])) if coll else (0, n)
+    clo, chi = (7 * int(cbeg[rank]), 7 * int(cbeg[rank + 1])) if coll else (0, nc)
     own = slice(lo, hi)
     Dinv = np.zeros((n, n))
     for i in range(lo // 7, hi // 7):
         Dinv[7 * i:7 * i + 7, 7 * i:7 * i + 7] = omega * np.linalg.inv(A[7 * i:7 * i + 7, 7 * i:7 * i + 7])
-    # Galerkin product: a rank holds its own block rows, so its product is a partial sum
+    # Galerkin product of this rank's rows: COMPLETE rows of its own aggregates, nothing elsewhere
     Ac = P[own].T @ (A[own] - lam * np.eye(n)[own]) @ P
     if coll:
-        coll[0](Ac.reshape(-1), 0)
+        outside = np.ones(nc, bool)
+        outside[clo:chi] = False
+        assert not Ac[outside].any()
+        coll[1](Ac.reshape(-1), (nc * 7 * np.asarray(cbeg)).astype(np.int64), rank)   # owners' rows, all-gathered
     Ainv_c = np.linalg.inv(Ac + lam * (P.T @ P))  # damping carried as lambda W, W = P^T P (replicated)
+    if coll:
+        srows, sseg, rrows, rseg = plan
+        sidx = (7 * srows[:, None] + np.arange(7)[None, :]).reshape(-1)
+        ridx = (7 * rrows[:, None] + np.arange(7)[None, :]).reshape(-1)
+        soffs, roffs = (7 * sseg).astype(np.int64), (7 * rseg).astype(np.int64)
+        need = np.zeros(n, bool)  # the rows this rank's blocks read
+        need[lo:hi] = True
+        need[ridx] = True
+        assert not (A[own][:, ~need] != 0).any()
 
-    def gather(v):
+    def exchange(v):  # neighbour exchange: exactly the rows the other side reads
         if coll:
-            coll[1](v, offs, rank)
+            recv = np.zeros(max(ridx.size, 1))
+            coll[2](np.ascontiguousarray(v[sidx]) if sidx.size else np.zeros(1), soffs, recv, roffs, rank)
+            v[ridx] = recv[:ridx.size]
 
     def precond(r, z0):  # z0 = omega D^-1 r on own rows (what the PCG step hands over)
         x = z0.copy()
-        gather(x)
+        exchange(x)
         t = r[own] - A[own] @ x
-        r1 = P[own].T @ t
+        r1 = P[own].T @ t              # complete on this rank's coarse rows, zero elsewhere
         if coll:
-            coll[0](r1, 0)
-        x = x + P @ (Ainv_c @ r1)          # every rank prolongs all rows: no collective
+            coll[1](r1, (7 * np.asarray(cbeg)).astype(np.int64), rank)
+        xc = Ainv_c @ r1               # replicated coarse level
+        x = x + P @ xc                 # own rows and the foreign rows read: xc is replicated, no collective
         out = np.zeros(n)
         out[own] = x[own] + Dinv[own, own] @ (r[own] - A[own] @ x)
-        gather(out)
+        exchange(out)
         return out
 
     x = np.zeros(n); r = np.zeros(n); p = np.zeros(n); sv = np.zeros(n)
@@ -230,7 +263,8 @@ def _amg_pcg(A, b, P, lam, lo, hi, offs, rank, coll):
         z = precond(r, z0)
         gamma_old, alpha_old = gamma, alpha
         it += 1
-    gather(x)
+    if coll:
+        coll[1](x, (7 * np.asarray(beg)).astype(np.int64), rank)
     return x, it
 
 
@@ -238,15 +272,12 @@ def _amg_worker(rank, world, port, out):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import dist_helpers as D
-    from sim3opt_amd import lib as L
     D.init(rank, world, port)
-    H, b, P = _amg_system()
+    H, b, P, beg, cbeg, plans = _amg_system(world)
     n = H.shape[0]
     lam = 1e-6 * np.abs(np.diag(H)).max()
     A = H + lam * np.eye(n)
-    offs = (7 * L.partition_rows_equal(n // 7, world)).astype(np.int64)
-    x, it = _amg_pcg(A, b, P, lam, int(offs[rank]), int(offs[rank + 1]), offs, rank,
-                     (D.allreduce, D.allgatherv))
+    x, it = _amg_pcg(A, b, P, lam, beg, cbeg, plans[rank], rank, (D.allreduce, D.allgatherv, D.alltoallv))
     if rank == 0:
         np.savez(out, x=x, it=it)
 
@@ -256,11 +287,18 @@ def test_partitioned_multigrid_pcg_over_gloo_matches_serial(tmp_path, world):
     out = str(tmp_path / "amg.npz")
     _spawn(_amg_worker, world, out)
     res = np.load(out)
-    H, b, P = _amg_system()
+    H, b, P, beg, cbeg, plans = _amg_system(world)
     n = H.shape[0]
     lam = 1e-6 * np.abs(np.diag(H)).max()
     A = H + lam * np.eye(n)
-    xs, its = _amg_pcg(A, b, P, lam, 0, n, None, 0, None)
+    # the halo plans of two ranks mirror each other: what p receives from q is what q sends to p, in order
+    for p in range(world):
+        for q in range(world):
+            sp, ssp, rp, rsp = plans[p]
+            sq, ssq, rq, rsq = plans[q]
+            assert np.array_equal(rp[rsp[q]:rsp[q + 1]], sq[ssq[p]:ssq[p + 1]])
+            assert p != q or rsp[q + 1] == rsp[q]
+    xs, its = _amg_pcg(A, b, P, lam, beg, cbeg, None, 0, None)
     xd = np.linalg.solve(A, b)
     assert np.abs(res["x"] - xd).max() < 1e-8 * np.abs(xd).max()
     assert np.abs(xs - xd).max() < 1e-8 * np.abs(xd).max()

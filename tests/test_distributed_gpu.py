@@ -25,7 +25,7 @@ def _free_port():
 COARSEST = ("SIM3OPT_AMG_COARSEST", "64")
 
 
-def _graph(prec=-1):
+def _graph(prec=0):
     from sim3opt_amd import synth
     synth.DRIFT_TARGET = 0.05
     if prec == 2:  # a three-level hierarchy with the dense level capped at 64 rows (COARSEST below):
@@ -33,7 +33,7 @@ def _graph(prec=-1):
     return synth.manhattan(300, 2500, dims=(7, 7, 4), per_cell=4)
 
 
-def _worker(rank, world, port, out, prec=-1):
+def _worker(rank, world, port, out, prec=0, neighbour=True):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import dist_helpers as D
@@ -45,7 +45,7 @@ def _worker(rank, world, port, out, prec=-1):
     G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
-    G.comm_init_callbacks(rank, world, D.allreduce, D.allgatherv)
+    D.attach(G, rank, world, neighbour)
     G.initialize()
     assert G.preconditioner_in_use() == (2 if prec == 2 else 0)
     lo, hi = G.local_rows()
@@ -65,23 +65,30 @@ def _worker(rank, world, port, out, prec=-1):
              pcg=[s.pcg_iters for s in st])
 
 
-@pytest.mark.parametrize("world,prec", [(2, -1), (3, -1), (2, 2), (3, 2)])
-def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec):
-    """prec = 2: the multigrid preconditioner with its level 0 row-partitioned (all-reduced Galerkin
-    products and restricted residuals, replicated coarse levels)."""
+@pytest.mark.parametrize("world,prec,shard,neighbour", [(2, 0, 0, True), (3, 0, 0, False), (2, 2, 0, True),
+                                                        (3, 2, 100, True), (4, 2, 100, True), (3, 2, 100, False)])
+def test_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec, shard, neighbour):
+    """prec = 2: the multigrid preconditioner on a row partition -- aggregates never straddle two ranks, so
+    Galerkin products and restrictions need no reduction; shard = 100: level 1 (167 rows) is partitioned by
+    owner like level 0, with its own exchanges, and the first replicated level gets the owners' pieces by
+    all-gather; neighbour = False: no alltoallv callback -- every exchange falls back to the all-gather of
+    the whole vector."""
     from sim3opt_amd import lib as L, synth
     out = str(tmp_path / "r")
+    if shard:
+        monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", str(shard))
     # (one retry on a fresh port, only if the TCP rendezvous itself lost a race for the port)
     H.spawn_with_port_retry(
-        lambda: mp.spawn(_worker, args=(world, _free_port(), out, prec), nprocs=world, join=True))
+        lambda: mp.spawn(_worker, args=(world, _free_port(), out, prec, neighbour), nprocs=world, join=True))
     res = [np.load(out + f".{r}.npz") for r in range(world)]
     if prec == 2:
         monkeypatch.setenv(*COARSEST)
-    # (a partitioned graph numbers its block rows in locality order; the single-process run it is
-    # compared with does the same, so that both build the same multigrid hierarchy)
-    monkeypatch.setenv("SIM3OPT_ROW_ORDER", "bfs")
+    # (a partitioned graph numbers its block rows in locality order and aggregates inside the ranks' spans;
+    # the single-process run it is compared with does the same, so that both build the same hierarchy and
+    # run the same cycle)
     g = _graph(prec)
-    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec)
+    G = L.Graph(fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=prec, row_order=1,
+                amg_virtual_ranks=world)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     G.initialize()
@@ -111,7 +118,7 @@ def test_two_process_row_partition_matches_single(tmp_path, monkeypatch, world, 
         assert abs(float(r["regrown_chi"]) - float(res[0]["regrown_chi"])) < 1e-12 * float(res[0]["regrown_chi"])
 
 
-@pytest.mark.parametrize("prec", [-1, 2])
+@pytest.mark.parametrize("prec", [0, 2])
 def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     """The RCCL transport (dlopen, ncclCommInitRank, in-place ncclAllReduce, grouped in-place
     ncclBroadcast on the engine's stream) exercised with one rank: every collective of the
@@ -139,7 +146,11 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     npcg = sum(s.pcg_iters for s in A.stats())
     assert ct["n_allreduce"] >= npcg and ct["n_allgather"] >= npcg  # at least one of each per PCG iteration
     assert ct["ms_allreduce"] > 0 and ct["ms_allgather"] > 0
-    assert ct["bytes_allgather"] >= ct["n_allgather"] * 7 * 8 * (len(g["states"]) - 1)
+    # (one rank has no neighbours: the level-0 exchanges fall back to the all-gather of the whole vector -- one
+    # per PCG iteration with block-Jacobi, two with the multigrid cycle, which also adds the small all-gathers
+    # of the first replicated level)
+    assert ct["bytes_allgather"] >= (2 if prec == 2 else 1) * npcg * 7 * 8 * (len(g["states"]) - 1)
+    assert ct["n_exchange"] == 0
     A.kernel_times(reset=True)
     assert A.comm_times()["n_allreduce"] == 0 and A.comm_times()["ms_allgather"] == 0
     monkeypatch.delenv("SIM3OPT_FORCE_COMM")
@@ -170,7 +181,7 @@ def _worker_cfg3(rank, world, port, out):
     G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
-    G.comm_init_callbacks(rank, world, D.allreduce, D.allgatherv)
+    D.attach(G, rank, world)
     G.initialize()
     lo, hi = G.local_rows()
     chi0 = G.chi2()
@@ -207,8 +218,7 @@ def _check_cfg3(res, world, monkeypatch):
     # against the single-process run of the same graph in the same row order
     synth.DRIFT_TARGET = 0.05
     g = synth.manhattan()
-    monkeypatch.setenv("SIM3OPT_ROW_ORDER", "bfs")
-    G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8)
+    G = L.Graph(fix_small_angle_b=1, pcg_rel_tol=1e-8, row_order=1, amg_virtual_ranks=world)
     G.add_vertices(g["states"], g["fixed"])
     G.add_edges(g["v0"], g["v1"], g["meas"])
     G.initialize()
@@ -253,7 +263,7 @@ def test_config4_full_size_graph_row_partitioned_over_8_ranks(monkeypatch):
         G = L.Graph(device=0, fix_small_angle_b=1, pcg_rel_tol=1e-8)
         G.add_vertices(g["states"], g["fixed"])
         G.add_edges(g["v0"], g["v1"], g["meas"])
-        G.comm_init_callbacks(rank, world, tg.allreduce(rank), tg.allgatherv(rank))
+        tg.attach(G, rank)
         G.initialize()
         lo, hi = G.local_rows()
         chi0 = G.chi2()

@@ -687,6 +687,34 @@ def test_config3_manhattan_full_size_properties():
     assert synth.rmse(G.get_vertices(), g["gt"]) < synth.rmse(g["states"], g["gt"])
 
 
+def test_batched_rejected_trials_equal_sequential_solves():
+    """After a rejected LM trial the dampings of the next trials are known (g2o: lambda *= nu, nu *= 2), so their
+    systems are solved together -- one pass over the blocks for up to four vectors (engine_batch.hip) -- and the
+    trials evaluated in g2o's order.  Same trial counts, same lambda, same chi2, same estimates as solving them
+    one after the other (options.pcg_batch = 1): bit for bit -- per system the batched kernels perform the
+    one-system kernels' operations in the same order.  delta = 1e-9: LM reaches the noise floor of the
+    numeric Jacobians after a few iterations and rejects trials in bursts (what the benchmark window shows)."""
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(3000, 30000, dims=(17, 17, 10))
+    runs = []
+    for batch in (1, 0):
+        G = mk(g, fix_small_angle_b=1, pcg_rel_tol=1e-8, preconditioner=2, pcg_batch=batch)
+        assert G.preconditioner_in_use() == 2
+        n = G.optimize(30)
+        st = G.stats()
+        kt = G.kernel_times()
+        runs.append(dict(n=n, trials=[s.trials for s in st], lam=[s.lambda_ for s in st], chi=[s.chi2_after for s in st],
+                         pcg=[s.pcg_iters for s in st], states=G.get_vertices(), batches=int(kt.n_batches),
+                         solves=int(kt.n_batched_solves)))
+    seq, bat = runs
+    print("trials", seq["trials"], "batches", bat["batches"], "systems in batches", bat["solves"])
+    assert seq["batches"] == 0 and bat["batches"] >= 2 and bat["solves"] >= 2 * bat["batches"]
+    assert max(seq["trials"]) >= 3  # (there were bursts of rejected trials to batch)
+    assert seq["n"] == bat["n"] and seq["trials"] == bat["trials"] and seq["pcg"] == bat["pcg"]
+    assert seq["lam"] == bat["lam"] and seq["chi"] == bat["chi"]
+    assert np.array_equal(seq["states"], bat["states"])
+
+
 def test_overcorrected_cycle_falls_back_instead_of_failing_the_trial(monkeypatch):
     """The multigrid cycle scales its coarse corrections by 1.8 / 1.6, which is safe
     only while the inexact coarse solves stay within (0, 2) of the exact ones.  Forced beyond that
