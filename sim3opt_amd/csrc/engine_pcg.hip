@@ -39,9 +39,15 @@ int Engine::level_part_init(int l, int32_t nb_l, const int32_t* rowptr_l, const 
   halo_plan(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), comm.rank, srows, sseg, rrows, rseg);
   lp.n_send = (int32_t)srows.size();
   lp.n_recv = (int32_t)rrows.size();
-  // (a partition without locality -- insertion order of a graph that wanders -- has nearly every row on its
-  // boundary, towards nearly every rank: the plain all-gather is cheaper then)
-  lp.neighbour = (int64_t)lp.n_send + lp.n_recv < (int64_t)nb_l;
+  // Neighbour exchange or whole-vector all-gather: decided from the boundary rows of ALL ranks, so that every
+  // rank takes the same branch (a collective all ranks must enter alike).  A partition without locality --
+  // insertion order of a graph that wanders -- has nearly every row on its boundary, towards nearly every
+  // rank: the plain all-gather is cheaper then.
+  {
+    std::vector<int32_t> brows, bseg;
+    boundary_rows(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), brows, bseg);
+    lp.neighbour = 4 * (int64_t)brows.size() < 3 * (int64_t)nb_l;
+  }
   if (opt.verbose)
     std::fprintf(stderr, "sim3opt: rank %d of %d, level %d: rows [%d, %d) of %d; sends %d rows, receives %d: %s\n",
                  comm.rank, comm.world, l, lp.lo, lp.hi, nb_l, lp.n_send, lp.n_recv,
