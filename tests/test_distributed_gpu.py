@@ -112,8 +112,12 @@ def test_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec
         assert abs(float(r["chi0"]) - chi0) < 1e-10 * chi0
         # vs the single-process run: only summation order differs
         assert np.allclose(r["chi"], [s.chi2_after for s in st], rtol=1e-7)
-        # (1500-vertex graph of the multigrid case: PCG-tolerance-level differences times the
-        # conditioning of the late, lightly damped systems)
+        # Two runs that solve the same systems to pcg_rel_tol = 1e-12 with other summation orders differ by up to
+        # ~ tol * cond(H + lambda I) per step.  Measured (scripts/cond_of_test_graphs.py,
+        # profiles/r4_condition_numbers.json, dense eigenvalues at the oracle's state after 4 LM iterations):
+        # the 1500-vertex graph of the multigrid case -- lambda 6.1e-5, eig(H) in [4.3e-4, 238], cond 4.8e5,
+        # tol * cond 4.8e-7 per step (the stopping test is in the M^-1 norm, which can leave the 2-norm an order
+        # above that); measured RMSE 4.8e-6, bound 2e-5.  The 300-vertex graph: cond 1.5e4, bound 1e-6.
         assert synth.rmse(r["states"], G.get_vertices()) < (2e-5 if prec == 2 else 1e-6)
         assert abs(float(r["regrown_chi"]) - float(res[0]["regrown_chi"])) < 1e-12 * float(res[0]["regrown_chi"])
 
@@ -166,6 +170,8 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     assert np.allclose([s.chi2_after for s in A.stats()], [s.chi2_after for s in B.stats()],
                        rtol=1e-6 if prec == 2 else 1e-9)
     from sim3opt_amd import synth
+    # (pcg_rel_tol = 1e-10 here; cond(H + lambda I) of the two graphs 4.8e5 / 1.5e4, profiles/r4_condition_numbers.json:
+    # tol * cond = 4.8e-5 / 1.5e-6 bounds what two preconditioners' converged steps may differ by)
     assert synth.rmse(A.get_vertices(), B.get_vertices()) < (2e-5 if prec == 2 else 1e-7)
 
 
