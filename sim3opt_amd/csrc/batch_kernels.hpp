@@ -44,6 +44,19 @@ void k_spmv_span_k(int nb, const int32_t* __restrict__ wrow,
     if (threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
   }
+  // gridDim.y > 1 (coarse levels: launch-latency-bound, the matrix sits in cache): every slice of the grid
+  // takes K of the systems -- more wavefronts instead of longer ones
+  if (gridDim.y > 1) {
+    const size_t s0 = (size_t)blockIdx.y * K;
+    p += s0 * bs.vec;
+    q += s0 * bs.vec;
+    if (rvec) rvec += s0 * bs.vec;
+    if (Minv) Minv += s0 * bs.minv;
+    if (MODE == 3) partials_r += s0 * bs.xc;
+    if (DIAGK) diagk += s0 * bs.diag;
+    if (partials) partials += s0 * bs.part;
+    if (sc) sc += s0;
+  }
   // per-system damping (level 0: a scalar added at the row end; coarse levels carry it in their per-system
   // diagonal blocks, DIAGK); a finished system's vectors are computed along and ignored by the PCG step
   double lam[K];
@@ -502,6 +515,13 @@ __global__ __launch_bounds__(WG) void k_amg_restrict_k(int nc, const int32_t* __
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / 7, rr = lane % 7, base = lane - rr;
+  if (gridDim.y > 1) {  // every slice of the grid takes K of the systems
+    const size_t s0 = (size_t)blockIdx.y * K;
+    t_f += s0 * vs_f;
+    r_c += s0 * vs_c;
+    x_c += s0 * vs_c;
+    if (Minv_c) Minv_c += s0 * ms_c;
+  }
   for (int a0 = (blockIdx.x * 4 + wave) * 9; a0 < nc; a0 += gridDim.x * 36) {
     const int a = a0 + sub;
     const bool act = lane < 63 && a < nc;
@@ -575,6 +595,12 @@ __global__ __launch_bounds__(WG) void k_amg_dense_apply_k(int n, const double* _
                                                           const double* __restrict__ r, double* __restrict__ x,
                                                           int64_t as, int64_t vs) {
   const int lane = threadIdx.x & 63;
+  if (gridDim.y > 1) {  // every slice of the grid takes K of the systems
+    const size_t s0 = (size_t)blockIdx.y * K;
+    Ainv += s0 * as;
+    r += s0 * vs;
+    x += s0 * vs;
+  }
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
 #pragma unroll
     for (int s = 0; s < K; ++s) {

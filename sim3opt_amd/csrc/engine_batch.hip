@@ -31,6 +31,8 @@ int Engine::batch_alloc(std::string& err) {
     HIPCHK(hipMemsetAsync(p, 0, sizeof(double) * std::max<size_t>(count, 1), stream));
     return SIM3OPT_OK;
   };
+  // (schedule only -- the results do not depend on it: which levels run one system per grid slice)
+  if (const char* ev = std::getenv("SIM3OPT_BATCH_SLICE_BLOCKS")) b_slice_blocks = std::atoll(ev);
   b_vs = pad64(n);
   double** v0[] = {&b_x, &b_r, &b_z, &b_p, &b_q, &b_s, &b_az};
   for (double** v : v0) {
@@ -95,8 +97,21 @@ void Engine::b_spmv_mode(int level, int mode, const double* v, double* out, cons
                      L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0, rz_part, rvec,          \
                      const_cast<double*>(xc), level == 0 ? d_bsc : (DevScalars*)nullptr, (const double*)B.Minv, 1,  \
                      (const int32_t*)L.agg, over, bs, (const float*)B.diag32))
+  // a level whose blocks stay in cache (<= b_slice_blocks: levels >= 2 of config 3) runs one system per grid
+  // slice: its passes are launch-latency-bound, four times the wavefronts cost what one set costs, while one
+  // wavefront carrying four systems takes 2.5x as long (measured)
+#define BSPMV_SLICED(MODEV)                                                                                        \
+  hipLaunchKernelGGL((k_spmv_span_k<8, false, MODEV, float, 1, true>), dim3(L.span_grid, b_nsys), dim3(WG), 0,     \
+                     stream, L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0, rz_part, rvec,  \
+                     const_cast<double*>(xc), (DevScalars*)nullptr, (const double*)B.Minv, 1,                      \
+                     (const int32_t*)L.agg, over, bs, (const float*)B.diag32)
+  if (level > 0 && L.nnzb <= b_slice_blocks) {
+    if (mode == 1) BSPMV_SLICED(1); else if (mode == 3) BSPMV_SLICED(3); else BSPMV_SLICED(2);
+    return;
+  }
   if (level == 0) { if (mode == 1) BSPMV(SIM3OPT_F32_CH, true, 1, false); else BSPMV(SIM3OPT_F32_CH, true, 2, false); }
   else { if (mode == 1) BSPMV(8, false, 1, true); else if (mode == 3) BSPMV(8, false, 3, true); else BSPMV(8, false, 2, true); }
+#undef BSPMV_SLICED
 #undef BSPMV
 }
 
@@ -108,9 +123,9 @@ void Engine::b_restrict(int l, const double* t) {
   if (l == 0)
     BATCH_DISPATCH(b_nsys, hipLaunchKernelGGL((k_amg_restrict0_k<KS>), dim3((Cc.nb + 3) / 4), dim3(WG), 0, stream, Cc.nb,
                        F.mptr, F.mem, d_P, t, BC.r, Minv_c, BC.x, (const DevScalars*)d_bsc, BF.vs, BC.vs, BC.ms));
-  else
-    BATCH_DISPATCH(b_nsys, hipLaunchKernelGGL((k_amg_restrict_k<KS>), dim3(grid_for((Cc.nb + 8) / 9, 4)), dim3(WG), 0,
-                       stream, Cc.nb, F.mptr, F.mem, t, BC.r, Minv_c, BC.x, BF.vs, BC.vs, BC.ms));
+  else  // (coarse vectors are a few MB at most: one system per grid slice, see b_spmv_mode)
+    hipLaunchKernelGGL((k_amg_restrict_k<1>), dim3(grid_for((Cc.nb + 8) / 9, 4), b_nsys), dim3(WG), 0, stream, Cc.nb,
+                       F.mptr, F.mem, t, BC.r, Minv_c, BC.x, BF.vs, BC.vs, BC.ms);
 }
 
 double* Engine::b_coarse(int l) {
@@ -118,8 +133,8 @@ double* Engine::b_coarse(int l) {
   const AmgLevel& Cc = amg[l + 1];
   const BatchLevel& BC = blv[l + 1];
   if (l + 2 == nl) {
-    BATCH_DISPATCH(b_nsys, hipLaunchKernelGGL((k_amg_dense_apply_k<KS>), dim3(std::max(1, std::min(256, (7 * Cc.nb + 3) / 4))),
-                       dim3(WG), 0, stream, 7 * Cc.nb, (const double*)b_Ainv, (const double*)BC.r, BC.x, b_as, BC.vs));
+    hipLaunchKernelGGL((k_amg_dense_apply_k<1>), dim3(std::max(1, std::min(256, (7 * Cc.nb + 3) / 4)), b_nsys), dim3(WG), 0,
+                       stream, 7 * Cc.nb, (const double*)b_Ainv, (const double*)BC.r, BC.x, b_as, BC.vs);
     return BC.x;
   }
   double* res = b_cycle(l + 1, BC.x, BC.t);

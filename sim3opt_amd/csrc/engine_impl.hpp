@@ -202,6 +202,7 @@ class Engine {
   DevScalars *d_bsc = nullptr, *h_bsc = nullptr;
   bool batch_ready = false;
   int b_nsys = KB;  // systems of the batch being solved (kernels are instantiated for 2, 3, 4)
+  int64_t b_slice_blocks = 100000;  // levels with at most this many blocks run one system per grid slice
   int batch_alloc(std::string& err);
   void batch_release();
   void b_spmv_mode(int level, int mode, const double* v, double* out, const double* rvec, const double* xc);
