@@ -21,8 +21,14 @@ struct BatchStrides {
 // bookkeeping are shared, everything that depends on the vector is an array over the systems.  Level 0 adds the
 // damping as lambda_s x at the row end; on a coarse level (DIAGK) the damping sits in the diagonal block, so
 // system s takes ITS diagonal block from diagk and the shared stream's diagonal block is skipped.
+#ifndef SIM3OPT_BATCH_WAVES
+#define SIM3OPT_BATCH_WAVES 0  // tuning: force this many wavefronts per SIMD (0: the compiler's choice)
+#endif
 template <int CH, bool NT, int MODE, typename VT, int K, bool DIAGK>
 __global__ __launch_bounds__(WG)
+#if SIM3OPT_BATCH_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(SIM3OPT_BATCH_WAVES, SIM3OPT_BATCH_WAVES)))
+#endif
 void k_spmv_span_k(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,

@@ -345,7 +345,7 @@ void Engine::amg_prolong(int l, const double* xc, const double* xin, double* xou
                        F.agg, (const double*)nullptr, xc, xin, xout, scp, amg_over);
   if (comm.active() && sharded(l) && !parts[l].neighbour) {  // (no neighbour plan: the whole vector travels)
     amg_exchange(l, xout);
-  } else if (comm.active() && sharded(l) && parts[l].n_recv > 0) {
+  } else if (comm.active() && sharded(l) && parts[l].n_recv > 0 && !parts[l].self_test) {  // (self-test: own rows)
     const int n = parts[l].n_recv, gl = grid_for((n + 8) / 9, 4);
     if (l == 0)
       hipLaunchKernelGGL((k_amg_prolong<true>), dim3(gl), dim3(WG), 0, stream, 0, n, (const int32_t*)parts[l].d_recv,

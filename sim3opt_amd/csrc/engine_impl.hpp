@@ -254,6 +254,7 @@ class Engine {
     std::vector<int64_t> offs;            // 7 * row_begin (doubles): spans of the whole-vector all-gather
     std::vector<int64_t> blk_offs;        // 49 * rowptr[row_begin]: spans of the level's block values
     bool neighbour = false;               // the neighbour-only plan below is in use
+    bool self_test = false;               // one rank, forced collectives: the plan sends a few rows to itself
     int32_t n_send = 0, n_recv = 0;       // rows this rank sends / receives per exchange
     int32_t *d_send = nullptr, *d_recv = nullptr;  // row lists, grouped by peer
     std::vector<int64_t> send_offs, recv_offs;     // world + 1, doubles, into the buffers

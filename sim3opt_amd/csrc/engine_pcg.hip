@@ -34,9 +34,20 @@ int Engine::level_part_init(int l, int32_t nb_l, const int32_t* rowptr_l, const 
     lp.offs[r] = 7 * (int64_t)row_begin_l[r];
     lp.blk_offs[r] = 49 * (int64_t)rowptr_l[row_begin_l[r]];
   }
-  if (comm.world <= 1 || !opt.halo_exchange || !comm.can_exchange()) return SIM3OPT_OK;
+  if (!opt.halo_exchange || !comm.can_exchange()) return SIM3OPT_OK;
   std::vector<int32_t> srows, sseg, rrows, rseg;
-  halo_plan(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), comm.rank, srows, sseg, rrows, rseg);
+  if (comm.world <= 1) {
+    // one rank with forced collectives (the transport's self-test): a plan that sends a few of the rank's rows
+    // to itself, so that pack -> grouped send / receive -> unpack run as they do between neighbours
+    if (!comm.force) return SIM3OPT_OK;
+    for (int32_t i = 0; i < std::min<int32_t>(nb_l, 64); ++i) srows.push_back(i);
+    rrows = srows;
+    sseg = {0, (int32_t)srows.size()};
+    rseg = sseg;
+    lp.self_test = true;
+  } else {
+    halo_plan(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), comm.rank, srows, sseg, rrows, rseg);
+  }
   lp.n_send = (int32_t)srows.size();
   lp.n_recv = (int32_t)rrows.size();
   // Neighbour exchange or whole-vector all-gather: decided from the boundary rows of ALL ranks, so that every
@@ -46,7 +57,7 @@ int Engine::level_part_init(int l, int32_t nb_l, const int32_t* rowptr_l, const 
   {
     std::vector<int32_t> brows, bseg;
     boundary_rows(nb_l, rowptr_l, colidx_l, comm.world, row_begin_l.data(), brows, bseg);
-    lp.neighbour = 4 * (int64_t)brows.size() < 3 * (int64_t)nb_l;
+    lp.neighbour = lp.self_test || 4 * (int64_t)brows.size() < 3 * (int64_t)nb_l;
   }
   if (opt.verbose)
     std::fprintf(stderr, "sim3opt: rank %d of %d, level %d: rows [%d, %d) of %d; sends %d rows, receives %d: %s\n",
@@ -81,6 +92,7 @@ int Engine::exchange_level(int l, double* vec, std::string& err) {
   if (lp.n_recv > 0)
     hipLaunchKernelGGL(k_rows_scatter, dim3((7 * lp.n_recv + WG - 1) / WG), dim3(WG), 0, stream, lp.n_recv,
                        (const int32_t*)lp.d_recv, (const double*)lp.d_rbuf, vec);
+  if (lp.self_test) return comm.allgatherv(vec, lp.offs, stream, err);  // (one rank: both transports' paths)
   return SIM3OPT_OK;
 }
 
