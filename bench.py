@@ -429,11 +429,11 @@ def main():
         n_vec = 2 if G.preconditioner_in_use() == 2 else 3
         spmv_bytes = blocks_local * (392 + 4) + (rows_local + 1) * 4 + n_vec * 7 * rows_local * 8
         # HBM bytes per SpMV launch from the last rocprofv3 --pmc collection (separate passes;
-        # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r3_pmc_spmv.json
+        # TCC_EA0_RDREQ x 128 B + WRITE_SIZE, gfx950 correction applied): profiles/r4_pmc_spmv.json
         traffic = None
         try:
             if world == 1 and args.vertices == 100000 and args.edges == 1000000:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_spmv.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_spmv.json")))
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         except Exception:
             traffic = None
@@ -448,7 +448,7 @@ def main():
             ach = spmv_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_spmv_span", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": ("profiles/r3_pmc_spmv.json: separate rocprofv3 --pmc passes of the same "
+                    "traffic_source": ("profiles/r4_pmc_spmv.json: separate rocprofv3 --pmc passes of the same "
                                        "kernel on the same graph, not a counter read in this run")
                     if traffic is not None else None,
                     "avg_launch_ms": avg_ms, "launches": int(kt.n_spmv),

@@ -409,6 +409,8 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
     int qmax = 0;
     // solutions of the next trials, solved together after a rejection (engine_batch.hip)
     struct { int n = 0, next = 0; double lam[KB]; int32_t iters[KB]; double rel[KB]; bool capped[KB]; } batch;
+    bool prev_ok = false, prev_capped = false;  // the previous trial's solve (of this LM iteration)
+    int32_t prev_pit = 0;
     auto elapsed = [&](int a, int b, double& acc) -> int {
       if (!phase_timing) return SIM3OPT_OK;
       float ms = 0.f;
@@ -432,7 +434,12 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
         // blocks for all of them -- and evaluated one after the other exactly as before; a trial that is
         // accepted leaves the rest unused.  Only systems the hierarchy would solve anyway: a damping-dominated
         // one (lambda >= the block-Jacobi gate, adaptive_prec) is cheaper on its own.
-        const int cap = qmax >= 1 ? std::min(batch_capacity(), opt.max_trials - qmax) : 0;
+        // ... and only while this iteration's solves behave: a batch runs until its LAST system is done, every
+        // iteration at the price of all of them, and one failing system sends the whole batch to the sequential
+        // path's fall-backs -- in the as-written arithmetic (solves of hundreds of iterations, break-downs, a
+        // capped one) that made the reference_arithmetic leg 1.7x SLOWER; there the trials stay sequential.
+        const bool calm = prev_ok && !prev_capped && prev_pit > 0 && prev_pit <= 100;
+        const int cap = qmax >= 1 && calm ? std::min(batch_capacity(), opt.max_trials - qmax) : 0;
         if (cap >= 2) {
           double gate = DBL_MAX;
           if (adaptive_prec && !trace_stale && mean_diag > 0.0) gate = bj_gate >= 0.0 ? bj_gate : 0.05 * mean_diag;
@@ -518,6 +525,9 @@ int Engine::optimize(int32_t max_iters, std::vector<sim3opt_iter_stats>& stats, 
           hipLaunchKernelGGL(k_copy_states, dim3((8 * nv + WG - 1) / WG), dim3(WG), 0, stream, nv,
                              (const Sim3*)d_backup, d_states);
       }
+      prev_ok = ok2;
+      prev_capped = last_capped;
+      prev_pit = pit;
       ++qmax;
     } while (rho < 0 && qmax < opt.max_trials);
     kt.ms_update += T.ms_update;
