@@ -176,6 +176,46 @@ def test_rccl_transport_single_rank_selftest(monkeypatch, prec):
     assert synth.rmse(A.get_vertices(), B.get_vertices()) < (2e-5 if prec == 2 else 1e-7)
 
 
+def test_partitioned_multigrid_with_information_and_huber_matches_oracle(monkeypatch):
+    """Dense information matrices and Huber kernels on the row partition (three thread-ranks, level 1 partitioned
+    by owner): every rank linearises its rows' edges with the weights, the hierarchy follows (Galerkin rows formed
+    by their owners), and the result is the oracle's (exact LDL^T), on every rank alike."""
+    from oracle import oracle as O
+    from sim3opt_amd import lib as L, synth
+    monkeypatch.setenv(*COARSEST)
+    monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", "100")
+    world = 3
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(1500, 15000, dims=(12, 12, 10))
+    rng = np.random.default_rng(21)
+    M = rng.standard_normal((len(g["v0"]), 7, 7)) * 0.3
+    inf = np.einsum("kij,klj->kil", M, M) + np.eye(7)
+    tg = H.ThreadGroup(world)
+
+    def rank_body(rank):
+        G = L.Graph(device=0, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=2)
+        G.add_vertices(g["states"], g["fixed"])
+        G.add_edges(g["v0"], g["v1"], g["meas"], info=inf, kernel=L.KERNEL_HUBER, kernel_delta=0.5)
+        tg.attach(G, rank)
+        G.initialize()
+        n = G.optimize(4)
+        out = dict(n=n, states=G.get_vertices(), chi=[s.chi2_after for s in G.stats()],
+                   trials=[s.trials for s in G.stats()], rel=[s.pcg_rel_res for s in G.stats()])
+        G.close()
+        return out
+
+    res = tg.run(rank_body)
+    OG = O.Graph(g["states"], g["fixed"], g["v0"], g["v1"], g["meas"],
+                 info=inf.transpose(0, 2, 1).reshape(-1, 49), kernel=1, kdelta=0.5)
+    it, tr = OG.optimize(4, O.default_options(fix_small_angle_b=1, fd_delta=1e-6, threads=8))
+    for r in res:
+        assert np.array_equal(r["states"], res[0]["states"]) and r["chi"] == res[0]["chi"]
+        assert r["n"] == it == 4 and r["trials"] == [t.trials for t in tr]
+        assert all(x <= 1e-12 for x in r["rel"])
+        assert np.allclose(r["chi"], [t.chi2_after for t in tr], rtol=1e-7)
+        assert synth.rmse(r["states"], OG.states) < 1e-4
+
+
 # ------------------------------------------------------------------ config 4: the 100k / 1M graph
 def _worker_cfg3(rank, world, port, out):
     import sys

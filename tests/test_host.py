@@ -102,6 +102,71 @@ def test_no_cpu_fallback_without_gpu():
         G.optimize(5)
 
 
+def test_tuning_knobs_are_options_and_environment_overrides_are_echoed(monkeypatch):
+    """The numeric tuning of the PCG path lives in sim3opt_options; a SIM3OPT_* environment variable is a debug
+    override applied by sim3opt_initialize and reported by sim3opt_get_options (host logic: works without a GPU --
+    the override is applied before the device is asked for)."""
+    G = L.Graph(amg_cycle=[1, 2, 2, 2], amg_over=[1.7, 1.5], amg_shard_rows=2000, pcg_batch=3)
+    o = G.options()
+    assert list(o.amg_cycle) == [1, 2, 2, 2] and list(o.amg_over) == [1.7, 1.5]
+    assert o.amg_shard_rows == 2000 and o.pcg_batch == 3
+    with pytest.raises(L.Sim3OptError):
+        G.set_options(amg_omega=0.0)
+    monkeypatch.setenv("SIM3OPT_AMG_CYCLE", "23")
+    monkeypatch.setenv("SIM3OPT_AMG_OVER", "1.9,1.7")
+    monkeypatch.setenv("SIM3OPT_ROW_ORDER", "bfs")
+    monkeypatch.setenv("SIM3OPT_NO_HALO", "1")
+    monkeypatch.setenv("SIM3OPT_PCG_BATCH", "1")
+    G.add_vertices(np.tile(I8, (3, 1)), [1, 0, 0])
+    G.add_edges([1, 2], [0, 1], np.tile(I8, (2, 1)))
+    try:
+        G.initialize()
+    except L.Sim3OptError as e:  # no GPU here: the overrides were applied before the device was asked for
+        assert e.code == L.ERR_NO_DEVICE
+    o = G.options()
+    assert list(o.amg_cycle) == [2, 3, 3, 3] and list(o.amg_over) == [1.9, 1.7]
+    assert o.row_order == 1 and o.halo_exchange == 0 and o.pcg_batch == 1
+    assert o.amg_shard_rows == 2000  # (no variable set: the caller's value stays)
+
+
+def test_partition_aware_hierarchy_and_halo_plan_host_side():
+    """Host parts of the multi-rank design (no GPU): with amg_virtual_ranks = N the aggregates stay inside the N
+    equal row spans (so Galerkin rows and restrictions need no reduction across ranks) and every rank's
+    neighbour plan mirrors its neighbours'."""
+    from sim3opt_amd import synth
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(1500, 15000, dims=(12, 12, 10))
+    for world in (2, 4, 8):
+        G = L.Graph(row_order=1, amg_virtual_ranks=world, amg_coarsest=64)
+        G.add_vertices(g["states"], g["fixed"])
+        G.add_edges(g["v0"], g["v1"], g["meas"])
+        rows, blocks, agg = G.amg_hierarchy()
+        assert len(rows) >= 3 and rows[0] == 1499
+        _, beg, bnd, _ = G.partition_plan(world)
+        first = 0
+        for r in range(world):
+            a = np.unique(agg[beg[r]:beg[r + 1]])
+            assert a[0] == first and a[-1] - a[0] + 1 == a.size  # contiguous, nothing shared with another rank
+            first = a[-1] + 1
+        assert first == rows[1]
+        plans = [G.halo_plan(world, r) for r in range(world)]
+        for p in range(world):
+            sp, ssp, rp, rsp = plans[p]
+            assert rsp[p + 1] == rsp[p] and ssp[p + 1] == ssp[p]  # nothing to itself
+            assert np.all((rp < beg[p]) | (rp >= beg[p + 1])) and np.all((sp >= beg[p]) & (sp < beg[p + 1]))
+            for q in range(world):
+                sq, ssq, rq, rsq = plans[q]
+                assert np.array_equal(rp[rsp[q]:rsp[q + 1]], sq[ssq[p]:ssq[p + 1]])
+            # what a rank sends is its boundary: the rows with a neighbour on another rank
+            assert len(np.unique(sp)) == bnd[p]
+        # the partition only forbids pairs across span borders: the hierarchy stays about as coarse as the
+        # unpartitioned one (the greedy matching is not monotone, hence "about")
+        G1 = L.Graph(row_order=1, amg_coarsest=64)
+        G1.add_vertices(g["states"], g["fixed"])
+        G1.add_edges(g["v0"], g["v1"], g["meas"])
+        assert abs(int(G1.amg_hierarchy()[0][1]) - int(rows[1])) <= 0.15 * rows[1]
+
+
 def test_nothing_to_optimise_conventions():
     G = L.Graph()
     assert G._L.sim3opt_optimize(G._g, 10) == -1  # empty graph: g2o returns -1
