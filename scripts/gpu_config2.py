@@ -1,7 +1,7 @@
 """BASELINE.json configs[1]: synthetic chain + loop graph, 10k vertices / 20k edges, 10 LM iterations on
 the GPU.  The CPU oracle cannot factor this graph (10 001 random long-range loops: an expander, the
 fill of any elimination order is near-dense), so only its linearisation + chi2 phases are timed -- an
-upper bound on its LM rate, as in bench.py's cpu_baseline.  Writes gpurun_out/r3_config2.json."""
+upper bound on its LM rate, as in bench.py's cpu_baseline.  Writes gpurun_out/r4_config2.json."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,4 +28,4 @@ for fixb in (1, 0):
         cpu_seconds_linearize_plus_chi2=t_cpu, cpu_cores=1, speedup_lower_bound=t_cpu / (t_gpu / max(n, 1)))
     print(json.dumps(out[f"fix_small_angle_b={fixb}"]), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r3_config2.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r4_config2.json"), "w"), indent=1)

@@ -3,7 +3,7 @@ loop constraints of loopConstraints.txt are added one at a time, and after each 
 iterations, g2o's stopping rule) runs warm-started from the previous solution.  Reference
 configuration (delta = 1e-9, B as written).  GPU (libsim3opt through the C-ABI: graph growth +
 sim3opt_initialize keeps the estimates) next to the CPU oracle doing the same.
-Writes gpurun_out/r3_incremental_fixb<0|1>.json.
+Writes gpurun_out/r4_incremental_fixb<0|1>.json.
 Usage: python scripts/gpu_incremental.py [max_iters=100] [--exact-b] [--no-cpu]"""
 import json
 import os
@@ -72,4 +72,4 @@ if "--no-cpu" not in sys.argv:
                cpu_iters_per_closure=[p["iters"] for p in cper], cpu_first=cper[:3], cpu_last=cper[-3:])
     print(json.dumps({k: v for k, v in out.items() if k.startswith(("cpu_", "rmse", "speed", "closures_w")) and not k.endswith(("first", "last"))}), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r3_incremental_fixb%d.json" % FIXB), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r4_incremental_fixb%d.json" % FIXB), "w"), indent=1)
