@@ -115,7 +115,8 @@ typedef struct sim3opt_options {
                                         (transport self-test)                                  [SIM3OPT_FORCE_COMM] */
   int32_t amg_shard_rows;   /* 4096  partitioned runs: multigrid levels with more block rows than this are
                                         partitioned by owner like level 0 (aggregates never straddle ranks), smaller
-                                        ones are replicated                                    [SIM3OPT_AMG_SHARD_ROWS] */
+                                        ones are replicated; with two or three ranks the threshold is 8x this value
+                                                                                               [SIM3OPT_AMG_SHARD_ROWS] */
   int32_t amg_virtual_ranks;/* 0     > 1 on ONE rank: build the hierarchy as an N-rank partition would (aggregates
                                         inside N equal row spans): what a partitioned run is compared with
                                                                                                [SIM3OPT_AMG_VIRTUAL_RANKS] */

@@ -86,9 +86,13 @@ int Engine::amg_bind(const Structure& s, std::string& err) {
   // Which coarse levels are partitioned like level 0 (multi-rank runs): those with more rows than
   // options.amg_shard_rows, except the dense one -- a replicated level costs every rank its whole cycle, a
   // partitioned one costs an exchange per matrix pass; below a few thousand rows both are latency and the
-  // replicated form needs no collective
+  // replicated form needs no collective.  With two or three ranks a partitioned level saves at
+  // most half / two thirds of its passes and the 2/3/3 cycle those runs keep visits level 1 twice (five more
+  // exchanges per PCG iteration): the threshold is eight times higher there (config 3's level 1, 12 k rows,
+  // stays replicated below four ranks; the model of DESIGN.md 7 gives 0.63 against 0.72 ms per iteration at N = 2)
+  const int64_t shard_rows = (int64_t)std::max(1, opt.amg_shard_rows) * (part_world() >= 4 ? 1 : 8);
   rep_level = 1;
-  while (rep_level < nl - 1 && H[rep_level].nb > std::max(1, opt.amg_shard_rows) && !H[rep_level].row_begin.empty())
+  while (rep_level < nl - 1 && H[rep_level].nb > shard_rows && !H[rep_level].row_begin.empty())
     ++rep_level;
   if (comm.active()) {
     parts.resize(rep_level);

@@ -66,11 +66,11 @@ def _worker(rank, world, port, out, prec=0, neighbour=True):
 
 
 @pytest.mark.parametrize("world,prec,shard,neighbour", [(2, 0, 0, True), (3, 0, 0, False), (2, 2, 0, True),
-                                                        (3, 2, 100, True), (4, 2, 100, True), (3, 2, 100, False)])
+                                                        (3, 2, 10, True), (4, 2, 100, True), (3, 2, 10, False)])
 def test_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec, shard, neighbour):
     """prec = 2: the multigrid preconditioner on a row partition -- aggregates never straddle two ranks, so
-    Galerkin products and restrictions need no reduction; shard = 100: level 1 (167 rows) is partitioned by
-    owner like level 0, with its own exchanges, and the first replicated level gets the owners' pieces by
+    Galerkin products and restrictions need no reduction; shard = 100 (10 below four ranks, where the
+    threshold counts eightfold): level 1 (167 rows) is partitioned by owner like level 0, with its own exchanges, and the first replicated level gets the owners' pieces by
     all-gather; neighbour = False: no alltoallv callback -- every exchange falls back to the all-gather of
     the whole vector."""
     from sim3opt_amd import lib as L, synth
@@ -183,7 +183,7 @@ def test_partitioned_multigrid_with_information_and_huber_matches_oracle(monkeyp
     from oracle import oracle as O
     from sim3opt_amd import lib as L, synth
     monkeypatch.setenv(*COARSEST)
-    monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", "100")
+    monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", "10")  # (three ranks: the threshold counts eightfold)
     world = 3
     synth.DRIFT_TARGET = 0.05
     g = synth.manhattan(1500, 15000, dims=(12, 12, 10))
