@@ -117,6 +117,16 @@ def init(rank, world, port):
                             world_size=world)
 
 
+def finish():
+    """Orderly end of a worker: everybody has left the last collective, then the group (and gloo's background
+    threads) is torn down before the interpreter exits -- a worker that simply returned could die in gloo's
+    thread teardown ("terminate called without an active exception"), which mp.spawn reports as a failure."""
+    try:
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 # bind-race messages only: "Connection reset" / "Connection refused" are also what the survivors print
 # when a peer died AFTER the rendezvous -- a worker fault, which must not be retried
 _RENDEZVOUS_MARKERS = ("Address already in use", "EADDRINUSE", "The server socket has failed")

@@ -103,6 +103,7 @@ def _worker(rank, world, port, out):
     assert m[0] == it
     if rank == 0:
         np.save(out, x)
+    D.finish()
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -280,6 +281,7 @@ def _amg_worker(rank, world, port, out):
     x, it = _amg_pcg(A, b, P, lam, beg, cbeg, plans[rank], rank, (D.allreduce, D.allgatherv, D.alltoallv))
     if rank == 0:
         np.savez(out, x=x, it=it)
+    D.finish()
 
 
 @pytest.mark.parametrize("world", [2, 8])

@@ -63,6 +63,7 @@ def _worker(rank, world, port, out, prec=0, neighbour=True):
              regrown_chi=regrown_chi,
              chi=[s.chi2_after for s in st], trials=[s.trials for s in st],
              pcg=[s.pcg_iters for s in st])
+    D.finish()
 
 
 @pytest.mark.parametrize("world,prec,shard,neighbour", [(2, 0, 0, True), (3, 0, 0, False), (2, 2, 0, True),
@@ -240,6 +241,7 @@ def _worker_cfg3(rank, world, port, out):
              chi=[s.chi2_after for s in st], trials=[s.trials for s in st],
              pcg=[s.pcg_iters for s in st], rel=[s.pcg_rel_res for s in st],
              rmse_gt=synth.rmse(G.get_vertices(), g["gt"]), rmse_gt0=synth.rmse(g["states"], g["gt"]))
+    D.finish()
 
 
 def _check_cfg3(res, world, monkeypatch):

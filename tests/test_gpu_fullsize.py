@@ -167,6 +167,7 @@ def _worker(rank, world, port, out):
     if rank == 0:
         rec["vor"] = G.partition_plan(world)[0]
     np.savez(out + f".{rank}.npz", **rec)
+    D.finish()
 
 
 def test_config4_every_ranks_rows_match_oracle(tmp_path):
