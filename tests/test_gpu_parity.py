@@ -689,20 +689,30 @@ def test_config3_manhattan_full_size_properties():
     assert synth.rmse(G.get_vertices(), g["gt"]) < synth.rmse(g["states"], g["gt"])
 
 
-def test_batched_rejected_trials_equal_sequential_solves():
+@pytest.mark.parametrize("graph,slice_blocks", [("manhattan", None), ("manhattan", 0), ("kitti", None)])
+def test_batched_rejected_trials_equal_sequential_solves(monkeypatch, graph, slice_blocks):
     """After a rejected LM trial the dampings of the next trials are known (g2o: lambda *= nu, nu *= 2), so their
     systems are solved together -- one pass over the blocks for up to four vectors (engine_batch.hip) -- and the
     trials evaluated in g2o's order.  Same trial counts, same lambda, same chi2, same estimates as solving them
     one after the other (options.pcg_batch = 1): bit for bit -- per system the batched kernels perform the
     one-system kernels' operations in the same order.  delta = 1e-9: LM reaches the noise floor of the
-    numeric Jacobians after a few iterations and rejects trials in bursts (what the benchmark window shows)."""
-    synth.DRIFT_TARGET = 0.05
-    g = synth.manhattan(3000, 30000, dims=(17, 17, 10))
+    numeric Jacobians after a few iterations and rejects trials in bursts (what the benchmark window shows).
+    Three cases: a three-level hierarchy with the coarse levels run one system per grid slice (the default for
+    levels whose blocks stay in cache) and with four systems per wavefront (slice_blocks = 0: the path the large
+    levels of config 3 take); KITTI-00 with all 118 loops through a two-level hierarchy (restriction straight
+    into the dense level)."""
+    if slice_blocks is not None:
+        monkeypatch.setenv("SIM3OPT_BATCH_SLICE_BLOCKS", str(slice_blocks))
+    if graph == "kitti":
+        g, iters = K.build_direct_graph(False), 40
+    else:
+        synth.DRIFT_TARGET = 0.05
+        g, iters = synth.manhattan(3000, 30000, dims=(17, 17, 10)), 30
     runs = []
     for batch in (1, 0):
         G = mk(g, fix_small_angle_b=1, pcg_rel_tol=1e-8, preconditioner=2, pcg_batch=batch)
         assert G.preconditioner_in_use() == 2
-        n = G.optimize(30)
+        n = G.optimize(iters)
         st = G.stats()
         kt = G.kernel_times()
         runs.append(dict(n=n, trials=[s.trials for s in st], lam=[s.lambda_ for s in st], chi=[s.chi2_after for s in st],
