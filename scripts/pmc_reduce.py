@@ -1,10 +1,10 @@
-"""Per-launch means of the PMC counters of k_spmv_span<8, true, 0> from rocprofv3 counter_collection CSVs."""
+"""Per-launch means of the PMC counters of the one-system PCG SpMV k_spmv_span<8, true, 0, double, 1, false> from rocprofv3 counter_collection CSVs."""
 import csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 acc = {}
 for f in glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_spmv_span<8, true, 0" not in r["Kernel_Name"]:
+        if "k_spmv_span<8, true, 0, double, 1, false>" not in r["Kernel_Name"]:  # (the one-system PCG SpMV)
             continue
         a = acc.setdefault(r["Counter_Name"], [0, 0.0])
         a[0] += 1

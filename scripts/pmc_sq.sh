@@ -18,7 +18,7 @@ import csv, glob, json, os
 acc = {}
 for f in glob.glob("gpurun_out/pmcsq/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_spmv_span<8, true, 0" not in r["Kernel_Name"]:
+        if "k_spmv_span<8, true, 0, double, 1, false>" not in r["Kernel_Name"]:
             continue
         a = acc.setdefault(r["Counter_Name"], [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {k: v[1] / v[0] for k, v in acc.items()}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / TA / TCC counters of the level-0 passes of the BATCHED solve (k_spmv_span_k, four systems) next to their
+# SQ / TA / TCC counters of the level-0 passes of the BATCHED solve (k_spmv_span<..., K = 4>) next to their
 # one-system twins, per-launch means -> gpurun_out/pmc_sq_batch.json.  Run on the GPU box (from the repo root).
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmcsqb
@@ -15,11 +15,11 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 cd $REPO && python3 - <<'PY'
 import csv, glob, json
-names = {"k_spmv_span<8, true, 0, double>": "one_system_pcg_spmv_fp64", "k_spmv_span<8, true, 1, float>": "one_system_residual_fp32",
-         "k_spmv_span<8, true, 2, float>": "one_system_smoothing_fp32",
-         "k_spmv_span_k<8, true, 0, double, 4, false>": "four_systems_pcg_spmv_fp64",
-         "k_spmv_span_k<8, true, 1, float, 4, false>": "four_systems_residual_fp32",
-         "k_spmv_span_k<8, true, 2, float, 4, false>": "four_systems_smoothing_fp32"}
+names = {"k_spmv_span<8, true, 0, double, 1, false>": "one_system_pcg_spmv_fp64", "k_spmv_span<8, true, 1, float, 1, false>": "one_system_residual_fp32",
+         "k_spmv_span<8, true, 2, float, 1, false>": "one_system_smoothing_fp32",
+         "k_spmv_span<8, true, 0, double, 4, false>": "four_systems_pcg_spmv_fp64",
+         "k_spmv_span<8, true, 1, float, 4, false>": "four_systems_residual_fp32",
+         "k_spmv_span<8, true, 2, float, 4, false>": "four_systems_smoothing_fp32"}
 acc = {}
 for f in glob.glob("gpurun_out/pmcsqb/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

@@ -16,8 +16,8 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 cd $REPO && python3 - <<'PY'
 import csv, glob, json
-names = {"k_spmv_span<8, true, 0, double>": "pcg_spmv_fp64", "k_spmv_span<8, true, 1, float>": "cycle_residual_fp32",
-         "k_spmv_span<8, true, 2, float>": "cycle_smoothing_fp32"}
+names = {"k_spmv_span<8, true, 0, double, 1, false>": "pcg_spmv_fp64", "k_spmv_span<8, true, 1, float, 1, false>": "cycle_residual_fp32",
+         "k_spmv_span<8, true, 2, float, 1, false>": "cycle_smoothing_fp32"}
 acc = {}
 for f in glob.glob("gpurun_out/pmcsq0/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

@@ -6,7 +6,9 @@ acc = {}
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]
     head = name.split("(")[0]
-    if "k_spmv_span" not in head or not (", 0>" in head or ", 0, double>" in head):
+    # the PCG's own SpMV: MODE 0 on FP64 blocks -- <CH, NT, 0, double[, K, DIAGK]>; the one-system kernel is
+    # K = 1 (since round 4 one template serves one and several right-hand sides)
+    if "k_spmv_span" not in head or not (", 0>" in head or ", 0, double>" in head or ", 0, double, 1, false>" in head):
         continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = acc.setdefault(name.split("(")[0], dict(all_n=0, all_us=0.0, work_n=0, work_us=0.0))

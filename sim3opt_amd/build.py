@@ -18,6 +18,7 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-result"]
+FLAGS += os.environ.get("SIM3OPT_EXTRA_FLAGS", "").split()  # (A/B experiments build twice in one gpurun call)
 # measurement prototypes (engine_proto.hip) are NOT part of the product library
 if os.environ.get("SIM3OPT_BENCH_HOOKS", "0") not in ("", "0"):
     FLAGS.append("-DSIM3OPT_BENCH_HOOKS")

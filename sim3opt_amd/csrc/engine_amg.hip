@@ -292,12 +292,12 @@ void Engine::spmv_mode(const AmgLevel& L, int mode, int level, const double* v, 
 hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0, stream, L.nb,  \
                    L.wrow, L.rowptr, L.colidx, L.vals, v, out, 0.0, rz_part, rvec,              \
                    const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
-                   (const int32_t*)L.agg, amg_over)
+                   (const int32_t*)L.agg, amg_over, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)
 #define AMG_SPMV32(NTV, MODEV)                                                                    \
 hipLaunchKernelGGL((k_spmv_span<(NTV) ? SIM3OPT_F32_CH : 8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
                    L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0,         \
                    rz_part, rvec, const_cast<double*>(xc),                                        \
-                   level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over)
+                   level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)
   if (amg_fp32) {
     if (level == 0) { if (mode == 1) AMG_SPMV32(true, 1); else AMG_SPMV32(true, 2); }
     else { if (mode == 1) AMG_SPMV32(false, 1); else if (mode == 3) AMG_SPMV32(false, 3); else AMG_SPMV32(false, 2); }

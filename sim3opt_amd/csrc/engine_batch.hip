@@ -8,7 +8,7 @@
 
 namespace sim3opt {
 
-#include "spmv_kernel.hpp"  // (FASTPATH, the one-system kernel this one mirrors)
+#include "spmv_kernel.hpp"
 #include "batch_kernels.hpp"
 
 static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
@@ -92,7 +92,7 @@ void Engine::b_spmv_mode(int level, int mode, const double* v, double* out, cons
   BatchStrides bs{B.vs, B.ms, level + 1 < (int)amg.size() ? blv[level + 1].vs : 0, B.ms, SPAN_GRID_MAX};
   const double over = amg_over;
 #define BSPMV(CHV, NTV, MODEV, DIAGV)                                                                              \
-  BATCH_DISPATCH(b_nsys, hipLaunchKernelGGL((k_spmv_span_k<CHV, NTV, MODEV, float, KS, DIAGV>), dim3(L.span_grid), \
+  BATCH_DISPATCH(b_nsys, hipLaunchKernelGGL((k_spmv_span<CHV, NTV, MODEV, float, KS, DIAGV>), dim3(L.span_grid), \
                      dim3(WG), 0, stream,   \
                      L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0, rz_part, rvec,          \
                      const_cast<double*>(xc), level == 0 ? d_bsc : (DevScalars*)nullptr, (const double*)B.Minv, 1,  \
@@ -101,7 +101,7 @@ void Engine::b_spmv_mode(int level, int mode, const double* v, double* out, cons
   // slice: its passes are launch-latency-bound, four times the wavefronts cost what one set costs, while one
   // wavefront carrying four systems takes 2.5x as long (measured)
 #define BSPMV_SLICED(MODEV)                                                                                        \
-  hipLaunchKernelGGL((k_spmv_span_k<8, false, MODEV, float, 1, true>), dim3(L.span_grid, b_nsys), dim3(WG), 0,     \
+  hipLaunchKernelGGL((k_spmv_span<8, false, MODEV, float, 1, true>), dim3(L.span_grid, b_nsys), dim3(WG), 0,     \
                      stream, L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0, rz_part, rvec,  \
                      const_cast<double*>(xc), (DevScalars*)nullptr, (const double*)B.Minv, 1,                      \
                      (const int32_t*)L.agg, over, bs, (const float*)B.diag32)
@@ -221,7 +221,7 @@ int Engine::pcg_batch(const double* lams, int nsys, int32_t* iters, double* rel_
     if (all || it >= max_it) break;
     const int todo = std::min(chunk, max_it - it);
     for (int c = 0; c < todo; ++c) {
-      BATCH_DISPATCH(nsys, hipLaunchKernelGGL((k_spmv_span_k<8, true, 0, double, KS, false>), dim3(gs), dim3(WG), 0, stream,
+      BATCH_DISPATCH(nsys, hipLaunchKernelGGL((k_spmv_span<8, true, 0, double, KS, false>), dim3(gs), dim3(WG), 0, stream,
                          nb, d_wrow, d_rowptr, d_colidx, (const double*)d_vals, (const double*)b_az, b_q, 0.0, b_part_a,
                          (const double*)nullptr, b_part_b, d_bsc, (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0,
                          bs0, (const float*)nullptr));

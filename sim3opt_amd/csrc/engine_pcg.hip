@@ -105,11 +105,11 @@ void Engine::spmv_raw(double lambda, const double* v, double* q, const double* r
 #define SPAN_CASE(CH, NTV)                                                                       \
 hipExtLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, ev0, ev1, 0, nb, \
                       d_wrow, d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec,         \
-                      d_part_b, scp, (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0)
+                      d_part_b, scp, (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)
 #define SPAN_PLAIN(CH, NTV)                                                                     \
 hipLaunchKernelGGL((k_spmv_span<CH, NTV, 0>), dim3(g), dim3(WG), 0, stream, nb, d_wrow,       \
                    d_rowptr, d_colidx, d_vals, v, q, lambda, d_part_a, rvec, d_part_b, scp,     \
-                   (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0)
+                   (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)
   if (!ev0) {  // plain launch: capturable into a hipGraph
     if (spmv_chunk <= 4) { if (spmv_nt) SPAN_PLAIN(4, true); else SPAN_PLAIN(4, false); }
     else { if (spmv_nt) SPAN_PLAIN(8, true); else SPAN_PLAIN(8, false); }

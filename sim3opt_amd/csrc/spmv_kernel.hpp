@@ -1,6 +1,8 @@
 // spmv_kernel.hpp -- the software-pipelined 7x7 block-CSR SpMV with its multigrid epilogues (a template:
-// instantiated by engine_pcg.hip for the PCG's own product and by engine_amg.hip for the cycle's matrix
-// passes).  LinearSolverEigen's role, kitti_surf.cpp:553-554; SURVEY.md 8(a) row a9.
+// instantiated by engine_pcg.hip for the PCG's own product, by engine_amg.hip for the cycle's matrix passes and by
+// engine_batch.hip for K right-hand sides at once -- ONE kernel source: the one-system kernel is K = 1; measured
+// on the driver's command: 47.1-47.2 LM it/s against 46.6-46.9 with a separate one-system kernel).
+// LinearSolverEigen's role, kitti_surf.cpp:553-554; SURVEY.md 8(a) row a9.
 #pragma once
 // q = (H + lambda I) p with the partial dot products p.q and (optionally) rvec.p per workgroup --
 // the block-CSR SpMV of the PCG (LinearSolverEigen's role, kitti_surf.cpp:553-554).
@@ -28,10 +30,30 @@
 #define SIM3OPT_SPMV_FASTPATH 1
 #endif
 constexpr bool FASTPATH = SIM3OPT_SPMV_FASTPATH != 0;
-template <int CH, bool NT, int MODE, typename VT = double>
+
+// K > 1 (engine_batch.hip: the rejected trials of one LM iteration, solved together): the block stream, the
+// column indices and the row bookkeeping are shared, everything that depends on the vector is an array over the
+// systems; vectors of system s live at base + s * stride (BatchStrides).  Level 0 adds the damping as lambda_s x
+// at the row end; on a coarse level (DIAGK) the damping sits in the diagonal block, so system s takes ITS
+// diagonal block from diagk and the shared stream's diagonal block is skipped.  Per system the operations and
+// their order are those of K = 1 (0 + d x is exact): the K solutions are bit for bit K one-system results.
+// gridDim.y > 1: every slice of the grid takes K of the systems (coarse levels: launch-latency-bound).
+struct BatchStrides {
+  int64_t vec;   // between the systems' vectors of this level (doubles)
+  int64_t minv;  // between their smoother inverses (49 doubles per row)
+  int64_t xc;    // between their coarse corrections (mode 3; vectors of the next level)
+  int64_t diag;  // between their damped diagonal blocks (coarse levels; 49 floats per row)
+  int part;      // between their arrays of partial sums
+};
+
+#ifndef SIM3OPT_BATCH_WAVES
+#define SIM3OPT_BATCH_WAVES 0  // tuning: force this many wavefronts per SIMD (0: the compiler's choice)
+#endif
+template <int CH, bool NT, int MODE, typename VT = double, int K = 1, bool DIAGK = false>
 __global__ __launch_bounds__(WG)
-// (no occupancy floor: the FP32 smoothing pass at 88 VGPRs / 5 wavefronts per SIMD without spills runs 0.5-1 %
-// faster end to end than forced to 80 VGPRs / 6 wavefronts with 3-5 spilled registers; r3_negative_results.log)
+#if SIM3OPT_BATCH_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(SIM3OPT_BATCH_WAVES, SIM3OPT_BATCH_WAVES)))
+#endif
 void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ colidx,
@@ -44,21 +66,47 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
                                                   DevScalars* __restrict__ sc,
                                                   const double* __restrict__ Minv, int lam_sc,
                                                   const int32_t* __restrict__ agg,
-                                                  double xc_scale) {
-  __shared__ double sh[4];
-  __shared__ double sh2[4];
+                                                  double xc_scale, BatchStrides bs,
+                                                  const float* __restrict__ diagk) {
+  __shared__ double sh[K][4];
+  __shared__ double sh2[K][4];
   __shared__ int sh_cnt;
   if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
     if (threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
   }
+  // gridDim.y > 1 (coarse levels: launch-latency-bound, the matrix sits in cache): every slice of the grid
+  // takes K of the systems -- more wavefronts instead of longer ones
+  if (gridDim.y > 1) {
+    const size_t s0 = (size_t)blockIdx.y * K;
+    p += s0 * bs.vec;
+    q += s0 * bs.vec;
+    if (rvec) rvec += s0 * bs.vec;
+    if (Minv) Minv += s0 * bs.minv;
+    if (MODE == 3) partials_r += s0 * bs.xc;
+    if (DIAGK) diagk += s0 * bs.diag;
+    if (partials) partials += s0 * bs.part;
+    if (sc) sc += s0;
+  }
+  // per-system damping (level 0: a scalar added at the row end; coarse levels carry it in their per-system
+  // diagonal blocks, DIAGK); a finished system's vectors are computed along and ignored by the PCG step
+  double lam[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) lam[s] = lambda;
   if (sc) {
-    if (sc->done) return;
-    if (lam_sc) lambda = sc->lambda;  // captured launches cannot carry a per-solve kernel argument
-    // the previous update was the last allowed one: later launches become no-ops
+    bool all_done = true;
+#pragma unroll
+    for (int s = 0; s < K; ++s) all_done = all_done && sc[s].done;
+    if (all_done) return;
+    if (lam_sc) {
+#pragma unroll
+      for (int s = 0; s < K; ++s) lam[s] = sc[s].lambda;
+    }
     if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-      if (sc->stop) sc->done = 1;
-      sc->n_spmv_work += 1;  // (launches are stream-ordered: one writer at a time)
+#pragma unroll
+      for (int s = 0; s < K; ++s)
+        if (sc[s].stop) sc[s].done = 1;
+      sc[0].n_spmv_work += 1;  // (launches are stream-ordered: one writer at a time)
     }
   }
   const int lane = threadIdx.x & 63;
@@ -69,46 +117,60 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
   constexpr int NG = (CH + 7) / 8;  // shared gathers of p per chunk: eight blocks each
   const int gu = lane / 7 < 8 ? lane / 7 : 7, gc = lane % 7;
   const int rA = wrow[w], rB = wrow[w + 1];
-  double pq = 0.0, pr = 0.0;
+  double pq[K], pr[K];
   // per-row operands are requested when the row starts and consumed when it ends
-  double pi_n = 0.0, rv_n = 0.0, mv = 0.0;
+  double pi_n[K], rv_n[K], mv[K], acc[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) pq[s] = pr[s] = pi_n[s] = rv_n[s] = mv[s] = acc[s] = 0.0;
+  int kfirst = 0;  // index of the current row's first (= diagonal) block
   // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
   // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
   // instruction per row; the kernel is bound by the number of those, not by their bytes)
-  auto row_begin = [&](int row, int u, const double* xg) {
-    pi_n = __shfl(xg[u / 8], 7 * (u % 8) + r);
-    if (rvec) rv_n = rvec[(size_t)7 * row + r];
-    if (MODE >= 2) mv = Minv[(size_t)49 * row + l49];  // symmetric: entry (r, c49)
+  auto row_begin = [&](int row, int u, const double (*xg)[NG]) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      pi_n[s] = __shfl(xg[s][u / 8], 7 * (u % 8) + r);
+      if (rvec) rv_n[s] = rvec[(size_t)s * bs.vec + (size_t)7 * row + r];
+      if (MODE >= 2) mv[s] = Minv[(size_t)s * bs.minv + (size_t)49 * row + l49];  // symmetric: entry (r, c49)
+      // the row's own (per-system, damped) diagonal block times its own entries of the input: what the single
+      // system's stream adds first (0 + d x is exact, so the row sum is bit for bit the one-system sum)
+      if (DIAGK)
+        acc[s] = (double)diagk[(size_t)s * bs.diag + (size_t)49 * row + l49] * __shfl(xg[s][u / 8], 7 * (u % 8) + c49);
+      else
+        acc[s] = 0.0;
+    }
   };
   // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
   // (row sums are valid in lanes 0..6)
-  auto row_end = [&](int row, double acc) {
-    double y = acc;
+  auto row_end = [&](int row) {
 #pragma unroll
-    for (int cc = 1; cc < 7; ++cc) y += __shfl(acc, r + 7 * cc);
-    const double pi = pi_n;
-    y += lambda * pi;
-    if (MODE == 0) {
-      if (lane < 7) {
-        q[(size_t)7 * row + lane] = y;
-        pq += pi * y;
-        if (rvec) pr += rv_n * pi;
-      }
-    } else {
-      const double d = rv_n - y;
-      if (MODE == 1) {
-        if (lane < 7) q[(size_t)7 * row + lane] = d;
-      } else {
-        const double pr_ = mv * __shfl(d, c49);  // Minv(r, c) d_c
-        double o = pr_;
+    for (int s = 0; s < K; ++s) {
+      double y = acc[s];
 #pragma unroll
-        for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
+      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc[s], r + 7 * cc);
+      const double pi = pi_n[s];
+      y += lam[s] * pi;
+      double* qs = q + (size_t)s * bs.vec;
+      if (MODE == 0) {
         if (lane < 7) {
-          const double zo = pi + o;
-          q[(size_t)7 * row + lane] = zo;
-          // the PCG's r.z where z is born (level 0's last pass writes z = M^-1 r and holds r): the
-          // SpMV that follows then needs no load of r -- 11 us of its 166 (measured)
-          if (MODE == 2 && partials) pr += rv_n * zo;
+          qs[(size_t)7 * row + lane] = y;
+          pq[s] += pi * y;
+          if (rvec) pr[s] += rv_n[s] * pi;
+        }
+      } else {
+        const double d = rv_n[s] - y;
+        if (MODE == 1) {
+          if (lane < 7) qs[(size_t)7 * row + lane] = d;
+        } else {
+          const double pr_ = mv[s] * __shfl(d, c49);  // Minv(r, c) d_c
+          double o = pr_;
+#pragma unroll
+          for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
+          if (lane < 7) {
+            const double zo = pi + o;
+            qs[(size_t)7 * row + lane] = zo;
+            if (MODE == 2 && partials) pr[s] += rv_n[s] * zo;
+          }
         }
       }
     }
@@ -149,23 +211,29 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
     int cbase = k0;
     int cv = cbase + lane < kend ? colidx[cbase + lane] : 0;
     int cvn = cbase + 64 + lane < kend ? colidx[cbase + 64 + lane] : 0;
-    double acc = 0.0;
     VT vc[CH], vn[CH];
-    double xgc[NG], xgn[NG];
-    auto gather = [&](int ks, double* xg) {
+    double xgc[K][NG], xgn[K][NG];
+    auto gather = [&](int ks, double (*xg)[NG]) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int kk = ks + 8 * g + gu < kend ? ks + 8 * g + gu : kend - 1;
         const int colu = __shfl(cv, kk - cbase);
-        xg[g] = p[(size_t)7 * colu + gc];
-        if (MODE == 3) xg[g] += xc_scale * partials_r[(size_t)7 * agg[colu] + gc];
+        const int ag = MODE == 3 ? agg[colu] : 0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          xg[s][g] = p[(size_t)s * bs.vec + (size_t)7 * colu + gc];
+          if (MODE == 3) xg[s][g] += xc_scale * partials_r[(size_t)s * bs.xc + (size_t)7 * ag + gc];
+        }
       }
     };
 #pragma unroll
-    for (int g = 0; g < NG; ++g) xgn[g] = 0.0;
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) xgn[s][g] = 0.0;
     // prologue: chunk at k0
     load_chunk(k0, vc);
     gather(k0, xgc);
+    kfirst = kbeg;
     row_begin(row, kbeg - k0, xgc);
     for (int k = k0; k < kend; k += CH) {
       const int kn = k + CH;
@@ -186,9 +254,9 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
       // (profiles/r3_negative_results.log)
       const bool interior = FASTPATH && k >= kbeg && k + CH <= kend;
       auto next_row = [&](int u) {  // row `row` is complete; block u of this chunk starts the next one
-        row_end(row, acc);
-        acc = 0.0;
+        row_end(row);
         ++row;
+        kfirst = k + u;
         row_begin(row, u, xgc);
         if (row - rbase >= 64) {
           rbase += 64;
@@ -196,14 +264,18 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
         }
         k1 = __builtin_amdgcn_readlane(rpv, row - rbase);
       };
-      if (interior && k1 >= k + CH) {
+      // (DIAGK: a chunk may hold the row's diagonal block, which is replaced per system: the tested path)
+      if (interior && k1 >= k + CH && !(DIAGK && kfirst >= k)) {
 #pragma unroll
-        for (int h = 0; h < CH; h += 4) {  // (four at a time: eight live values cost the FP32 smoothing pass its occupancy)
-          double xs[4];
+        for (int h = 0; h < CH; h += 4) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xs[u] = __shfl(xgc[(h + u) / 8], 7 * ((h + u) % 8) + c49);
+          for (int s = 0; s < K; ++s) {
+            double xs[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc += (double)vc[h + u] * xs[u];
+            for (int u = 0; u < 4; ++u) xs[u] = __shfl(xgc[s][(h + u) / 8], 7 * ((h + u) % 8) + c49);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[s] += (double)vc[h + u] * xs[u];
+          }
         }
       } else {
 #pragma unroll
@@ -211,43 +283,62 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
           const int kk = k + u;
           if (kk >= kbeg && kk < kend) {
             if (kk == k1) next_row(u);
-            acc += (double)vc[u] * __shfl(xgc[u / 8], 7 * (u % 8) + c49);
+            const double vv = DIAGK && kk == kfirst ? 0.0 : (double)vc[u];
+#pragma unroll
+            for (int s = 0; s < K; ++s) acc[s] += vv * __shfl(xgc[s][u / 8], 7 * (u % 8) + c49);
           }
         }
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) vc[u] = vn[u];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) xgc[g] = xgn[g];
+      for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xgc[s][g] = xgn[s][g];
     }
-    row_end(row, acc);  // last row of the span
+    row_end(row);  // last row of the span
   }
+  // barrier-free partial sums per system (see k_spmv_span): the wavefront that arrives last adds the four in
+  // index order -- the same sums in the same order as the one-system kernel
   if (MODE == 2 && partials) {
-    // no barrier at the end of a streaming kernel: every wavefront leaves its sum in LDS and goes;
-    // the one that arrives last adds the four in index order (deterministic) and writes the partial
-    const double t = wave_sum(pr);
+    double t[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) t[s] = wave_sum(pr[s]);
     if (lane == 0) {
-      sh[threadIdx.x >> 6] = t;
+#pragma unroll
+      for (int s = 0; s < K; ++s) sh[s][threadIdx.x >> 6] = t[s];
       __threadfence_block();
       if (atomicAdd(&sh_cnt, 1) == 3) {
         __threadfence_block();
-        partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+          partials[(size_t)s * bs.part + blockIdx.x] = (sh[s][0] + sh[s][1]) + (sh[s][2] + sh[s][3]);
       }
     }
     return;
   }
   if (MODE != 0) return;
-  {  // the same barrier-free partial sums (w.z, and r.z when this pass reads r)
-    const double s = wave_sum(pq);
-    const double t = rvec ? wave_sum(pr) : 0.0;
+  {
+    double sa[K], sb[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      sa[s] = wave_sum(pq[s]);
+      sb[s] = rvec ? wave_sum(pr[s]) : 0.0;
+    }
     if (lane == 0) {
-      sh[threadIdx.x >> 6] = s;
-      sh2[threadIdx.x >> 6] = t;
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        sh[s][threadIdx.x >> 6] = sa[s];
+        sh2[s][threadIdx.x >> 6] = sb[s];
+      }
       __threadfence_block();
       if (atomicAdd(&sh_cnt, 1) == 3) {
         __threadfence_block();
-        if (partials) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        if (rvec) partials_r[blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          if (partials) partials[(size_t)s * bs.part + blockIdx.x] = (sh[s][0] + sh[s][1]) + (sh[s][2] + sh[s][3]);
+          if (rvec) partials_r[(size_t)s * bs.part + blockIdx.x] = (sh2[s][0] + sh2[s][1]) + (sh2[s][2] + sh2[s][3]);
+        }
       }
     }
   }
