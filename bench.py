@@ -475,6 +475,8 @@ def main():
                        # the tuning options the run used (sim3opt_get_options after initialize: environment
                        # overrides included) and the SIM3OPT_* variables that were set
                        "solver_options": solver_options(G),
+                       # what the automatic choices resolved to (levels, levels partitioned over the ranks, cycle)
+                       "multigrid_in_use": G.amg_in_use(),
                        "env_overrides": {k: v for k, v in os.environ.items() if k.startswith("SIM3OPT_")}},
             "edges_iters_per_s": args.edges * K / dt,
             "chi2_initial": chi2_0, "chi2_final": chi2_final,

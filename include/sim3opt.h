@@ -264,6 +264,11 @@ int sim3opt_preconditioner_in_use(const sim3opt_graph* g);
 /* Linear solver of this (initialized) graph: 1 exact sparse block Cholesky, 0 PCG (what
  * `linear_solver = -1` resolved to); negative = error code. */
 int sim3opt_linear_solver_in_use(const sim3opt_graph* g);
+/* What the automatic multigrid choices resolved to on this (initialized) graph: levels of the hierarchy
+ * (0: none), how many of them are partitioned over the ranks (0 on one rank), visits of levels 1, 2, 3, >= 4 per
+ * visit of the level above (options.amg_cycle = 0 picks {2,3,3,3}, or {1,2,2,2} from four ranks on).  Any
+ * pointer may be NULL. */
+int sim3opt_amg_in_use(const sim3opt_graph* g, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]);
 /* Plan of the exact sparse block Cholesky (LinearSolverEigen's role, kitti_surf.cpp:553-554) for this
  * graph: host only, no GPU needed, may be called before initialize.  Block column j of L is block row
  * perm[j] of the system (nested-dissection order); its stored 7x7 blocks are colptr[j]..colptr[j+1]

@@ -512,6 +512,13 @@ int sim3opt_preconditioner_in_use(const sim3opt_graph* g) {
   return engine_preconditioner(g->engine);
 }
 
+int sim3opt_amg_in_use(const sim3opt_graph* g, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]) {
+  if (!g) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return SIM3OPT_ERR_STATE;
+  engine_amg_in_use(g->engine, n_levels, n_partitioned, visits);
+  return SIM3OPT_OK;
+}
+
 int sim3opt_linear_solver_in_use(const sim3opt_graph* g) {
   if (!g) return SIM3OPT_ERR_ARG;
   if (!g->initialized) return SIM3OPT_ERR_STATE;

@@ -686,6 +686,13 @@ int engine_preconditioner(const Engine* e) { return e->use_amg ? 2 : (e->use_cha
 
 int engine_linear_solver(const Engine* e) { return e->use_direct ? 1 : 0; }
 
+void engine_amg_in_use(const Engine* e, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]) {
+  if (n_levels) *n_levels = e->use_amg ? (int32_t)e->amg.size() : 0;
+  if (n_partitioned) *n_partitioned = e->use_amg ? e->n_sharded : 0;
+  if (visits)
+    for (int l = 0; l < 4; ++l) visits[l] = e->use_amg ? e->amg_visits[l + 1] : 0;
+}
+
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset) {
   if (out) *out = e->kt;
   if (reset) {

@@ -165,6 +165,7 @@ SYMBOLS = {
     "sim3opt_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _up]),
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sim3opt_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
+    "sim3opt_amg_in_use": (C.c_int, [_vp, _ip, _ip, _ip]),
     "sim3opt_halo_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, _ip, _ip, _ip]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, C.POINTER(C.c_int64)]),
@@ -541,6 +542,13 @@ class Graph:
         if rc < 0:
             self._chk(rc)
         return rc
+
+    def amg_in_use(self):
+        """dict(levels, partitioned_levels, cycle): what the automatic multigrid choices resolved to."""
+        nl, ns = C.c_int32(), C.c_int32()
+        v = np.zeros(4, dtype=np.int32)
+        self._chk(self._L.sim3opt_amg_in_use(self._g, C.byref(nl), C.byref(ns), _p(v, _ip)))
+        return dict(levels=nl.value, partitioned_levels=ns.value, cycle=[int(x) for x in v])
 
     def system_pattern(self):
         """(rowptr, colidx) of the block-CSR system; host only."""

@@ -319,6 +319,8 @@ def test_config4_full_size_graph_row_partitioned_over_8_ranks(monkeypatch):
         n = G.optimize(3)
         st = G.stats()
         _, _, bnd, cut = G.partition_plan(world)
+        mg = G.amg_in_use()  # the N-aware choices: levels 0-1 partitioned, cycle 1/2/2 from four ranks on
+        assert mg["levels"] == 4 and mg["partitioned_levels"] == 2 and mg["cycle"][:3] == [1, 2, 2]
         V = G.get_vertices()
         res = dict(pos=synth.positions(V), scale=V[:, 7].copy(), chi0=chi0, n=n, rows=[lo, hi],
                    prec=G.preconditioner_in_use(), n_halo=int(bnd.sum()), cut_edges=cut,
