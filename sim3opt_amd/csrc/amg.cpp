@@ -159,25 +159,39 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
       const int32_t p = bo.passes[std::min<size_t>(levels.size() - 1, 2)];  // tuning knob: passes per level
       if (p >= 1 && p <= 6) npass = p;
     }
-    // owner of every node of the (repeatedly coarsened) matching graph: clusters stay inside one rank's span
+    // Owner of every node of the (repeatedly coarsened) matching graph: clusters stay inside one rank's span --
+    // on the levels a multi-rank run PARTITIONS (level 0 and coarse levels above bo.shard_rows rows whose own
+    // rows have owners): their Galerkin rows and restrictions then need no reduction across ranks.  A level that
+    // will be replicated anyway aggregates freely; and where the constraint stalls the matching (a coarse level
+    // with a few rows per rank that are not connected among themselves) the level aggregates freely too and is
+    // marked: it must be replicated (respects_owner = false).
+    bool constrain = parted && !L.row_begin.empty() && (levels.size() == 1 || nb > bo.shard_rows);
     std::vector<int32_t> owner;
-    if (parted) {
-      owner.resize(nb);
-      for (int32_t r = 0; r < bo.world; ++r)
-        for (int32_t i = L.row_begin[r]; i < L.row_begin[r + 1]; ++i) owner[i] = r;
-    }
-    for (int pass = 0; pass < npass && nc > max_coarsest / 2; ++pass) {
-      std::vector<int32_t> cid;
-      const int32_t m = match_pass(g, cid, parted ? owner.data() : nullptr);
-      for (int32_t& a : agg) a = cid[a];
-      if (parted) {
-        std::vector<int32_t> oc(m);
-        for (int32_t i = 0; i < (int32_t)cid.size(); ++i) oc[cid[i]] = owner[i];
-        owner.swap(oc);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      std::iota(agg.begin(), agg.end(), 0);
+      nc = nb;
+      WGraph gm = g;
+      if (constrain) {
+        owner.resize(nb);
+        for (int32_t r = 0; r < bo.world; ++r)
+          for (int32_t i = L.row_begin[r]; i < L.row_begin[r + 1]; ++i) owner[i] = r;
       }
-      g = coarsen_graph(g, cid, m);
-      nc = m;
+      for (int pass = 0; pass < npass && nc > max_coarsest / 2; ++pass) {
+        std::vector<int32_t> cid;
+        const int32_t m = match_pass(gm, cid, constrain ? owner.data() : nullptr);
+        for (int32_t& a : agg) a = cid[a];
+        if (constrain) {
+          std::vector<int32_t> oc(m);
+          for (int32_t i = 0; i < (int32_t)cid.size(); ++i) oc[cid[i]] = owner[i];
+          owner.swap(oc);
+        }
+        gm = coarsen_graph(gm, cid, m);
+        nc = m;
+      }
+      if (nc <= nb - nb / 4 || !constrain || levels.size() == 1) break;
+      constrain = false;  // (stalled under the constraint: once more without it; level 0 is never released)
     }
+    L.respects_owner = constrain;
     if (nc > nb - nb / 4) {  // matching stalls (isolated rows, stars): no useful hierarchy
       why = "graph does not coarsen";
       return false;
@@ -206,7 +220,7 @@ bool build_amg_hierarchy(int32_t nb0, const int32_t* rowptr0, const int32_t* col
     });
     AmgLevelHost C;
     C.nb = nc;
-    if (parted) {  // clusters are numbered by their smallest row and never straddle: contiguous spans again
+    if (constrain) {  // clusters are numbered by their smallest row and never straddle: contiguous spans again
       C.row_begin.assign(bo.world + 1, 0);
       for (int32_t a = 0; a < nc; ++a) ++C.row_begin[owner[a] + 1];
       for (int32_t r = 0; r < bo.world; ++r) C.row_begin[r + 1] += C.row_begin[r];

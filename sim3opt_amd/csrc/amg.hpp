@@ -34,11 +34,14 @@ struct AmgLevelHost {
   // a rank's coarse rows are exactly the aggregates of its own fine rows: Galerkin products and
   // restrictions need no reduction across ranks
   std::vector<int32_t> row_begin;
+  // this level's own aggregation stayed inside the ranks' spans (only then may the level be partitioned)
+  bool respects_owner = false;
 };
 
 struct AmgBuildOptions {
   int32_t max_coarsest = 256;       // most rows of the dense coarsest level (8 .. AMG_MAX_COARSEST)
   int32_t passes[3] = {0, 0, 0};    // matching passes on level 0, 1, >= 2; 0 = automatic
+  int32_t shard_rows = 0;           // coarse levels with more rows than this will be partitioned (and are constrained)
   int32_t world = 1;                // ranks of the row partition the aggregation must respect
   const int32_t* row_begin = nullptr;  // world + 1: level-0 spans (required when world > 1)
 };

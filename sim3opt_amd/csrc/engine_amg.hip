@@ -42,6 +42,7 @@ int Engine::amg_init(const Structure& s, bool automatic, std::string& err) {
   // names): aggregates never straddle two ranks
   std::vector<int32_t> vbegin;
   bo.world = part_world();
+  bo.shard_rows = (int32_t)std::min<int64_t>(INT32_MAX, (int64_t)std::max(1, opt.amg_shard_rows) * (part_world() >= 4 ? 1 : 8));
   if (comm.world > 1) {
     bo.row_begin = row_begin.data();
   } else if (bo.world > 1) {
@@ -92,7 +93,8 @@ int Engine::amg_bind(const Structure& s, std::string& err) {
   // stays replicated below four ranks; the model of DESIGN.md 7 gives 0.63 against 0.72 ms per iteration at N = 2)
   const int64_t shard_rows = (int64_t)std::max(1, opt.amg_shard_rows) * (part_world() >= 4 ? 1 : 8);
   rep_level = 1;
-  while (rep_level < nl - 1 && H[rep_level].nb > shard_rows && !H[rep_level].row_begin.empty())
+  while (rep_level < nl - 1 && H[rep_level].nb > shard_rows && !H[rep_level].row_begin.empty() &&
+         H[rep_level].respects_owner)
     ++rep_level;
   if (comm.active()) {
     parts.resize(rep_level);

@@ -217,6 +217,48 @@ def test_partitioned_multigrid_with_information_and_huber_matches_oracle(monkeyp
         assert synth.rmse(r["states"], OG.states) < 1e-4
 
 
+@pytest.mark.parametrize("world,verts,shard", [(8, 1500, 10), (4, 300, 1), (6, 300, 1)])
+def test_many_ranks_on_small_graphs(monkeypatch, world, verts, shard):
+    """Edge cases of the partitioned hierarchy: more ranks than a coarse level has rows to spare (8 ranks, level 1
+    with ~20 rows each; 300-vertex graph: level 1 with ~10 rows per rank, partitioned because the threshold is
+    forced down), ranks whose neighbour lists are short or one-sided.  Thread-ranks; identical results on all
+    ranks, the one-rank run with the same hierarchy to PCG tolerance."""
+    from sim3opt_amd import lib as L, synth
+    monkeypatch.setenv("SIM3OPT_AMG_COARSEST", "16")
+    monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", str(shard))
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(1500, 15000, dims=(12, 12, 10)) if verts == 1500 else \
+        synth.manhattan(300, 2500, dims=(7, 7, 4), per_cell=4)
+    tg = H.ThreadGroup(world)
+
+    def rank_body(rank):
+        G = L.Graph(device=0, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=2)
+        G.add_vertices(g["states"], g["fixed"])
+        G.add_edges(g["v0"], g["v1"], g["meas"])
+        tg.attach(G, rank)
+        G.initialize()
+        mg = G.amg_in_use()
+        n = G.optimize(4)
+        out = dict(n=n, states=G.get_vertices(), chi=[s.chi2_after for s in G.stats()], mg=mg,
+                   trials=[s.trials for s in G.stats()], rel=[s.pcg_rel_res for s in G.stats()])
+        G.close()
+        return out
+
+    res = tg.run(rank_body)
+    assert res[0]["mg"]["levels"] >= 3 and res[0]["mg"]["partitioned_levels"] >= 2
+    R = L.Graph(device=0, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-12, preconditioner=2, row_order=1,
+                amg_virtual_ranks=world)
+    R.add_vertices(g["states"], g["fixed"])
+    R.add_edges(g["v0"], g["v1"], g["meas"])
+    R.initialize()
+    assert R.optimize(4) == 4
+    for r in res:
+        assert np.array_equal(r["states"], res[0]["states"]) and r["chi"] == res[0]["chi"] and r["mg"] == res[0]["mg"]
+        assert r["n"] == 4 and r["trials"] == [s.trials for s in R.stats()] and all(x <= 1e-12 for x in r["rel"])
+        assert np.allclose(r["chi"], [s.chi2_after for s in R.stats()], rtol=1e-7)
+        assert synth.rmse(r["states"], R.get_vertices()) < 2e-5
+
+
 # ------------------------------------------------------------------ config 4: the 100k / 1M graph
 def _worker_cfg3(rank, world, port, out):
     import sys
