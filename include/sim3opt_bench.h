@@ -22,6 +22,11 @@ int sim3opt_bench_stream(sim3opt_graph* g, int32_t mode, int32_t reps, double* m
  * `reps` launches, out[2]: max difference to the product SpMV relative to max |q|, out[3]: bytes of its
  * stream.  Single GPU. */
 int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]);
+/* Measurement prototype (csrc/rowlane_proto.hpp): the cycle's level-0 FP32 passes with a group of 7 lanes per block
+ * row against the product kernel.  out[0..1]: ms of the product's residual / smoothing pass, out[2..3]: the
+ * prototype's, out[4..5]: the prototype's with four systems sharing the block stream, out[6..7]: max difference of
+ * the one-system results to the product's relative to max |q|.  Needs the multigrid hierarchy; single GPU. */
+int sim3opt_bench_spmv_rowlane(sim3opt_graph* g, int32_t reps, int32_t rows_per_group, double out[8]);
 #endif
 
 #ifdef __cplusplus

@@ -640,6 +640,11 @@ int sim3opt_bench_spmv_symmetric(sim3opt_graph* g, int32_t reps, double out[4]) 
   if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv_symmetric: call sim3opt_initialize first");
   return engine_bench_spmv_symmetric(g->engine, reps, out, g->err);
 }
+int sim3opt_bench_spmv_rowlane(sim3opt_graph* g, int32_t reps, int32_t rows_per_group, double out[8]) {
+  if (!g || !out || reps < 1) return fail(g, SIM3OPT_ERR_ARG, "bench_spmv_rowlane: bad argument");
+  if (!g->initialized) return fail(g, SIM3OPT_ERR_STATE, "bench_spmv_rowlane: call sim3opt_initialize first");
+  return engine_bench_spmv_rowlane(g->engine, reps, rows_per_group, out, g->err);
+}
 #endif
 
 int sim3opt_partition_rows(int32_t n_block_rows, const int32_t* rowptr, int32_t world,

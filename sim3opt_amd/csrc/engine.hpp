@@ -46,6 +46,7 @@ int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset);
 int engine_comm_times(Engine* e, sim3opt_comm_times* out);
 #ifdef SIM3OPT_BENCH_HOOKS
 int engine_bench_spmv_symmetric(Engine* e, int32_t reps, double out[4], std::string& err);
+int engine_bench_spmv_rowlane(Engine* e, int32_t reps, int32_t rows_per_group, double out[8], std::string& err);
 #endif
 
 }  // namespace sim3opt

@@ -7,6 +7,8 @@
 namespace sim3opt {
 
 #include "symm_proto.hpp"
+#include "spmv_kernel.hpp"
+#include "rowlane_proto.hpp"
 
 // Measurement prototype (symm_proto.hpp): out[0] = ms of phase 1, out[1] = ms of phase 2, out[2] = max
 // |difference| to the product SpMV relative to max |q|, out[3] = bytes of the upper-triangle stream
@@ -118,6 +120,118 @@ int engine_bench_spmv_symmetric(Engine* e, int32_t reps, double out[4], std::str
   out[1] = reps > 0 ? ms / reps : 0.0;
   out[3] = (double)nU * (392.0 + 4.0) + 2.0 * 56.0 * (double)(nU - nb) + 4.0 * (double)(nU - nb) +
            (double)(nb + 1) * 8.0 + 3.0 * 56.0 * (double)nb;
+  cleanup();
+  return hipGetLastError() == hipSuccess ? SIM3OPT_OK : SIM3OPT_ERR_HIP;
+}
+
+// Measurement prototype (rowlane_proto.hpp): the level-0 FP32 passes of the multigrid cycle with a group of 7 lanes
+// per block row (a block row per lane, in-lane products) against the product kernel, on the same matrix, vectors
+// and smoother inverses.  out[0..1] = ms of the product's residual / smoothing pass, out[2..3] = the prototype's,
+// out[4..5] = the prototype's with four systems sharing the block stream, out[6..7] = max |difference| of the
+// one-system results to the product's relative to max |q|.  `rows_per_group` block rows per lane group
+// (spans balanced by block count).  Needs the hierarchy (config 3); single GPU only.
+int engine_bench_spmv_rowlane(Engine* e, int32_t reps, int32_t rows_per_group, double out[8], std::string& err) {
+  if (!e->linearized || e->amg.empty() || !e->amg[0].vals32 || !e->amg[0].Minv) {
+    err = "bench_spmv_rowlane: needs a linearised system with the multigrid hierarchy set up (run optimize first)";
+    return SIM3OPT_ERR_STATE;
+  }
+  if (e->comm.active()) {
+    err = "bench_spmv_rowlane: single GPU only";
+    return SIM3OPT_ERR_STATE;
+  }
+  const Engine::AmgLevel& L = e->amg[0];
+  const int nb = L.nb;
+  const size_t n = (size_t)7 * nb;
+  constexpr int KS = 4;
+  std::vector<int32_t> rowptr(nb + 1);
+  HIPCHK(hipMemcpy(rowptr.data(), L.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+  const int nnzb = rowptr[nb];
+  // (rows_per_group > 64: the number of lane groups itself)
+  const int ngroups = rows_per_group > 64 ? std::min(nb, (int)rows_per_group)
+                                          : std::max(9, (nb + std::max(1, rows_per_group) - 1) / std::max(1, rows_per_group));
+  std::vector<int32_t> grow(ngroups + 1);
+  partition_rows(nb, rowptr.data(), ngroups, grow.data());
+  const int nwaves = (ngroups + 8) / 9, grid = (nwaves + 3) / 4;
+  std::vector<void*> tmp;
+  auto cleanup = [&]() { for (void* p : tmp) dev_free(p); };
+  auto alloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (dev_malloc(&p, bytes) != hipSuccess) return nullptr;
+    tmp.push_back(p);
+    return p;
+  };
+  int32_t* d_grow = (int32_t*)alloc(sizeof(int32_t) * grow.size());
+  float* d_v32 = (float*)alloc(sizeof(float) * 49 * (size_t)nnzb);
+  double* d_pv = (double*)alloc(sizeof(double) * n * KS);
+  double* d_rv = (double*)alloc(sizeof(double) * n * KS);
+  double* d_q = (double*)alloc(sizeof(double) * n * KS);
+  double* d_qref = (double*)alloc(sizeof(double) * n);
+  double* d_mi = (double*)alloc(sizeof(double) * 49 * (size_t)nb * KS);
+  double* d_part = (double*)alloc(sizeof(double) * (size_t)grid * 4 * KS);
+  if (!d_grow || !d_v32 || !d_pv || !d_rv || !d_q || !d_qref || !d_mi || !d_part) {
+    cleanup();
+    err = "bench_spmv_rowlane: hipMalloc";
+    return SIM3OPT_ERR_HIP;
+  }
+  hipStream_t st = e->stream;
+  (void)hipMemcpyAsync(d_grow, grow.data(), sizeof(int32_t) * grow.size(), hipMemcpyHostToDevice, st);
+  hipLaunchKernelGGL(k_rl_copy, dim3(4096), dim3(WG), 0, st, (size_t)49 * nnzb, (const double*)L.vals, d_v32);
+  for (int s = 0; s < KS; ++s) {  // input: the PCG's right-hand side and direction of the last solve (anything non-trivial)
+    (void)hipMemcpyAsync(d_pv + s * n, e->d_z, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(d_rv + s * n, e->d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(d_mi + (size_t)s * 49 * nb, L.Minv, sizeof(double) * 49 * (size_t)nb, hipMemcpyDeviceToDevice, st);
+  }
+  auto product = [&](int mode) {
+    if (mode == 1)
+      hipLaunchKernelGGL((k_spmv_span<SIM3OPT_F32_CH, true, 1, float>), dim3(L.span_grid), dim3(WG), 0, st, L.nb, L.wrow,
+                         L.rowptr, L.colidx, (const float*)L.vals32, (const double*)d_pv, d_qref, 0.0, (double*)nullptr,
+                         (const double*)d_rv, (double*)nullptr, (DevScalars*)nullptr, (const double*)L.Minv, 0,
+                         (const int32_t*)L.agg, 1.0, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr);
+    else
+      hipLaunchKernelGGL((k_spmv_span<SIM3OPT_F32_CH, true, 2, float>), dim3(L.span_grid), dim3(WG), 0, st, L.nb, L.wrow,
+                         L.rowptr, L.colidx, (const float*)L.vals32, (const double*)d_pv, d_qref, 0.0, e->d_part_b,
+                         (const double*)d_rv, (double*)nullptr, (DevScalars*)nullptr, (const double*)L.Minv, 0,
+                         (const int32_t*)L.agg, 1.0, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr);
+  };
+  auto proto = [&](int mode, int ks) {
+#define RL(MODEV, KV)                                                                                              \
+  hipLaunchKernelGGL((k_spmv_rowlane<MODEV, KV>), dim3(grid), dim3(WG), 0, st, ngroups, (const int32_t*)d_grow,       \
+                     (const int32_t*)L.rowptr, (const int32_t*)L.colidx, nnzb, (const float*)d_v32, (const double*)d_pv, \
+                     d_q, (const double*)d_rv, (const double*)d_mi, d_part, (int64_t)n, (int64_t)49 * nb)
+    if (mode == 1) { if (ks == 1) RL(1, 1); else RL(1, KS); }
+    else { if (ks == 1) RL(2, 1); else RL(2, KS); }
+#undef RL
+  };
+  std::vector<double> qa(n), qb(n);
+  for (int mode = 1; mode <= 2; ++mode) {
+    product(mode);
+    proto(mode, 1);
+    (void)hipMemcpyAsync(qa.data(), d_qref, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(qb.data(), d_q, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); err = "bench_spmv_rowlane: sync"; return SIM3OPT_ERR_HIP; }
+    double qmax = 0.0, dmax = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+      qmax = std::max(qmax, std::fabs(qa[k]));
+      dmax = std::max(dmax, std::fabs(qa[k] - qb[k]));
+    }
+    out[5 + mode] = qmax > 0 ? dmax / qmax : dmax;
+  }
+  auto timed = [&](auto&& launch) {
+    float ms = 0.f;
+    for (int w = 0; w < 3; ++w) launch();
+    (void)hipEventRecord(e->ev_a, st);
+    for (int w = 0; w < reps; ++w) launch();
+    (void)hipEventRecord(e->ev_b, st);
+    (void)hipEventSynchronize(e->ev_b);
+    (void)hipEventElapsedTime(&ms, e->ev_a, e->ev_b);
+    return reps > 0 ? (double)ms / reps : 0.0;
+  };
+  out[0] = timed([&]() { product(1); });
+  out[1] = timed([&]() { product(2); });
+  out[2] = timed([&]() { proto(1, 1); });
+  out[3] = timed([&]() { proto(2, 1); });
+  out[4] = timed([&]() { proto(1, KS); });
+  out[5] = timed([&]() { proto(2, KS); });
   cleanup();
   return hipGetLastError() == hipSuccess ? SIM3OPT_OK : SIM3OPT_ERR_HIP;
 }

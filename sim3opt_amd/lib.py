@@ -207,6 +207,7 @@ _lib = None
 
 OPTIONAL_SYMBOLS = {
     "sim3opt_bench_spmv_symmetric": (C.c_int, [_vp, C.c_int32, _dp]),
+    "sim3opt_bench_spmv_rowlane": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
 }
 
 
@@ -628,6 +629,12 @@ class Graph:
         the product SpMV, bytes of its stream)."""
         out = np.zeros(4)
         self._chk(self._L.sim3opt_bench_spmv_symmetric(self._g, int(reps), _p(out, _dp)))
+        return tuple(float(v) for v in out)
+
+    def bench_spmv_rowlane(self, reps=20, rows_per_group=2):
+        """Prototype of the row-per-lane FP32 passes (a SIM3OPT_BENCH_HOOKS build): 8 numbers, see sim3opt_bench.h."""
+        out = np.zeros(8)
+        self._chk(self._L.sim3opt_bench_spmv_rowlane(self._g, int(reps), int(rows_per_group), _p(out, _dp)))
         return tuple(float(v) for v in out)
 
     def bench_stream(self, mode, reps=20):
