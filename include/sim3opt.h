@@ -127,6 +127,11 @@ typedef struct sim3opt_options {
                                         deeper levels                                          [SIM3OPT_AMG_OVER=a0,a1] */
   int64_t direct_max_pairs; /* 0     most 7x7x7 block products of a factorisation the automatic rule accepts;
                                         0 = 300000 (3e7 with linear_solver = 1)               [SIM3OPT_DIRECT_MAX_PAIRS] */
+  int32_t debug_full_arrays;/* 0     partitioned runs allocate the block arrays (H, its FP32 copy, the partitioned
+                                        coarse levels, the assembly scratch) for the rank's own rows only; 1: whole
+                                        arrays with everything outside the rank's range poisoned (0xFF = NaN) and
+                                        checked after every linearisation / optimize -- a write there is an error,
+                                        a read shows as NaN (the test of the ranges)          [SIM3OPT_DEBUG_FULL_ARRAYS] */
 } sim3opt_options;
 
 /* Per-iteration record (g2o G2OBatchStatistics role; bal_example.cpp:55-56). */
@@ -269,6 +274,11 @@ int sim3opt_linear_solver_in_use(const sim3opt_graph* g);
  * visit of the level above (options.amg_cycle = 0 picks {2,3,3,3}, or {1,2,2,2} from four ranks on).  Any
  * pointer may be NULL. */
 int sim3opt_amg_in_use(const sim3opt_graph* g, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]);
+/* Device memory of the block arrays of this (initialized) graph on this rank -- H, its FP32 copy, the coarse levels'
+ * blocks, the assembly scratch: bytes[0] as allocated (a partitioned run holds its own rows only), bytes[1] what one
+ * rank holding the whole graph allocates for them.  (Vectors, edges and index arrays -- about a tenth of the total --
+ * are replicated and not counted.) */
+int sim3opt_device_bytes(const sim3opt_graph* g, int64_t bytes[2]);
 /* Plan of the exact sparse block Cholesky (LinearSolverEigen's role, kitti_surf.cpp:553-554) for this
  * graph: host only, no GPU needed, may be called before initialize.  Block column j of L is block row
  * perm[j] of the system (nested-dissection order); its stored 7x7 blocks are colptr[j]..colptr[j+1]

@@ -30,7 +30,8 @@ def body(rank):
     lo, hi = G.local_rows()
     out = dict(rank=rank, rows=[int(lo), int(hi)], lm_iters=int(n), pcg_iters=[int(s.pcg_iters) for s in st],
                trials=[int(s.trials) for s in st], chi2=[float(s.chi2_after) for s in st],
-               comm={k: (float(v) if isinstance(v, float) else int(v)) for k, v in ct.items()})
+               comm={k: (float(v) if isinstance(v, float) else int(v)) for k, v in ct.items()},
+               block_array_bytes=list(G.device_bytes()), debug_full_arrays=int(G.options().debug_full_arrays))
     if rank == 0:
         _, _, bnd, cut = G.partition_plan(N)
         o = G.options()
@@ -66,6 +67,8 @@ summary = dict(ranks=N, vertices=V, edges=E, transport="threads of one process, 
                boundary_rows_per_rank=r0["boundary_rows_per_rank"], cut_edges=r0["cut_edges"],
                amg_cycle_option=r0["amg_cycle_used"], amg_shard_rows=r0["amg_shard_rows"],
                per_rank=[per(r) for r in res],
+               block_array_MB_per_rank=[round(r["block_array_bytes"][0] / 1e6, 1) for r in res],
+               block_array_MB_one_rank=round(r0["block_array_bytes"][1] / 1e6, 1), debug_full_arrays=r0["debug_full_arrays"],
                identical_chi2_on_all_ranks=all(r["chi2"] == r0["chi2"] for r in res), rank0=r0)
 print(json.dumps({k: v for k, v in summary.items() if k not in ("rank0", "per_rank")}))
 print(json.dumps(dict(rank0=per(res[0]), worst_exchange_MB_per_pcg_iteration=max(p["exchange_MB_per_pcg_iteration"] for p in summary["per_rank"]))))

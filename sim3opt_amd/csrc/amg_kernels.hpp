@@ -140,10 +140,10 @@ __global__ __launch_bounds__(WG) void k_amg_galerkin(int cb0, int cb1, const int
 }
 
 // keeps the undamped Galerkin diagonal blocks (a trial overwrites the ones inside vals)
-__global__ __launch_bounds__(WG) void k_amg_copydiag(int nb, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(WG) void k_amg_copydiag(int lo, int hi, const int32_t* __restrict__ rowptr,
                                                      const double* __restrict__ vals,
-                                                     double* __restrict__ diagH) {
-  for (int idx = blockIdx.x * WG + threadIdx.x; idx < 49 * nb; idx += gridDim.x * WG)
+                                                     double* __restrict__ diagH) {  // rows [lo, hi): this rank's
+  for (int idx = 49 * lo + blockIdx.x * WG + threadIdx.x; idx < 49 * hi; idx += gridDim.x * WG)
     diagH[idx] = vals[(size_t)49 * rowptr[idx / 49] + idx % 49];
 }
 

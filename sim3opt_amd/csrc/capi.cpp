@@ -160,6 +160,7 @@ void sim3opt_options_default(sim3opt_options* o) {
   o->amg_over[0] = 1.8;
   o->amg_over[1] = 1.6;
   o->direct_max_pairs = 0;
+  o->debug_full_arrays = 0;
 }
 
 // Debug overrides: a SIM3OPT_* environment variable replaces the option field of the same name when the
@@ -194,6 +195,7 @@ static void apply_env_overrides(sim3opt_options& o) {
     if (const char* c = std::strchr(ev, ',')) o.amg_over[1] = std::atof(c + 1);
   }
   if (const char* ev = std::getenv("SIM3OPT_DIRECT_MAX_PAIRS")) o.direct_max_pairs = std::atoll(ev);
+  if (const char* ev = std::getenv("SIM3OPT_DEBUG_FULL_ARRAYS")) o.debug_full_arrays = std::atoi(ev) != 0;
 }
 
 sim3opt_graph* sim3opt_create(void) {
@@ -516,6 +518,13 @@ int sim3opt_amg_in_use(const sim3opt_graph* g, int32_t* n_levels, int32_t* n_par
   if (!g) return SIM3OPT_ERR_ARG;
   if (!g->initialized) return SIM3OPT_ERR_STATE;
   engine_amg_in_use(g->engine, n_levels, n_partitioned, visits);
+  return SIM3OPT_OK;
+}
+
+int sim3opt_device_bytes(const sim3opt_graph* g, int64_t bytes[2]) {
+  if (!g || !bytes) return SIM3OPT_ERR_ARG;
+  if (!g->initialized) return SIM3OPT_ERR_STATE;
+  engine_device_bytes(g->engine, bytes);
   return SIM3OPT_OK;
 }
 

@@ -28,11 +28,15 @@ void Engine::release_under_device() {
   // cached blocks are handed out again without the device-wide wait a hipFree implies
   if (stream) (void)hipStreamSynchronize(stream);
   void* ptrs[] = {d_states, d_backup, d_meas, d_ev0, d_ev1, d_hidx, d_active, d_info, d_kdelta,
-                  d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1, d_vals,
-                  d_scratch, d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
+                  d_rowptr, d_colidx, d_incptr, d_wrow, d_slot01, d_slot10, d_inc0, d_inc1,
+                  d_b, d_Minv, d_x, d_r, d_z, d_p, d_q, d_s, d_part_a, d_part_b, d_sc,
                   d_sub_first, d_sub_cnt, d_Gm, d_ptab};
   for (void* p : ptrs)
     if (p) dev_free(p);
+  for (const RangedArray& a : ranged)
+    if (a.alloc) dev_free(a.alloc);
+  ranged.clear();
+  d_vals = d_scratch = nullptr;
   for (void* p : amg_owned)
     if (p) dev_free(p);
   amg_owned.clear();
@@ -152,10 +156,13 @@ int Engine::init(const HostGraph& g, const Structure& s, std::string& err) {
   HIPCHK(upload(staged, stream, d_slot10, l_s10));
   HIPCHK(upload(staged, stream, d_inc0, l_i0));
   HIPCHK(upload(staged, stream, d_inc1, l_i1));
-  HIPCHK(dev_malloc((void**)&d_vals, sizeof(double) * 49 * (size_t)nnzb));
-  HIPCHK(hipMemset(d_vals, 0, sizeof(double) * 49 * (size_t)nnzb));
-  const size_t ninc = (size_t)s.incptr[nb];
-  HIPCHK(dev_malloc((void**)&d_scratch, sizeof(double) * 35 * std::max<size_t>(ninc, 1)));
+  // H and the assembly scratch: this rank's rows only (alloc_ranged; one rank: everything)
+  {
+    int rc = alloc_ranged(d_vals, 49 * (int64_t)s.rowptr[r0], 49 * (int64_t)s.rowptr[r1], 49 * (int64_t)nnzb, err);
+    if (rc) return rc;
+    rc = alloc_ranged(d_scratch, 35 * (int64_t)s.incptr[r0], 35 * (int64_t)s.incptr[r1], 35 * (int64_t)s.incptr[nb], err);
+    if (rc) return rc;
+  }
   HIPCHK(dev_malloc((void**)&d_Minv, sizeof(double) * 49 * (size_t)nb));
   // preconditioner choice: chain segments for chain-like graphs (few blocks per row)
   // automatic: chain segments only when almost every edge is a chain link (KITTI with one loop:
@@ -323,6 +330,34 @@ int Engine::chi2(double* out, std::string& err, hipEvent_t before_fetch, int sca
   if (rc) return rc;
   *out = h_sc->chi2;
   kt.n_chi2 += 1;
+  return SIM3OPT_OK;
+}
+
+// debug_full_arrays: nothing outside this rank's ranges may have been written (reads show as NaN in the results)
+int Engine::check_foreign_ranges(std::string& err) {
+  if (!opt.debug_full_arrays || ranged.empty()) return SIM3OPT_OK;
+  unsigned long long* d_cnt = nullptr;
+  HIPCHK(dev_malloc((void**)&d_cnt, sizeof(unsigned long long) * ranged.size()));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * ranged.size(), stream));
+  for (size_t i = 0; i < ranged.size(); ++i) {
+    const RangedArray& a = ranged[i];
+    const char* base = static_cast<const char*>(a.alloc);
+    const size_t head = (size_t)a.lo * a.elem / 4, tail0 = (size_t)a.hi * a.elem, tail = ((size_t)a.total * a.elem - tail0) / 4;
+    if (head) hipLaunchKernelGGL(k_count_unpoisoned, dim3(1024), dim3(WG), 0, stream, reinterpret_cast<const uint32_t*>(base), head, d_cnt + i);
+    if (tail) hipLaunchKernelGGL(k_count_unpoisoned, dim3(1024), dim3(WG), 0, stream, reinterpret_cast<const uint32_t*>(base + tail0), tail, d_cnt + i);
+  }
+  std::vector<unsigned long long> h(ranged.size(), 0);
+  hipError_t e1 = hipMemcpyAsync(h.data(), d_cnt, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, stream);
+  hipError_t e2 = hipStreamSynchronize(stream);
+  dev_free(d_cnt);
+  HIPCHK(e1);
+  HIPCHK(e2);
+  for (size_t i = 0; i < h.size(); ++i)
+    if (h[i]) {
+      err = "debug_full_arrays: " + std::to_string(h[i]) + " words outside this rank's range of ranged array " +
+            std::to_string(i) + " were written (rank " + std::to_string(comm.rank) + ")";
+      return SIM3OPT_ERR_STATE;
+    }
   return SIM3OPT_OK;
 }
 
@@ -579,9 +614,10 @@ void engine_take_comm(Engine* e, Comm* out) {
 }
 
 int engine_set_options(Engine* e, const sim3opt_options& opt) {
-  const int dev = e->opt.device;
+  const int dev = e->opt.device, full = e->opt.debug_full_arrays;  // (fixed at initialisation)
   e->opt = opt;
   e->opt.device = dev;
+  e->opt.debug_full_arrays = full;
   e->comm.timing = opt.time_kernels != 0;
   // (the events exist in any case: the flags may be set after sim3opt_initialize)
   e->phase_timing = opt.time_kernels != 0 || opt.verbose != 0 || e->nb > 4096;
@@ -590,7 +626,9 @@ int engine_set_options(Engine* e, const sim3opt_options& opt) {
 
 int engine_optimize(Engine* e, int32_t max_iters, std::vector<sim3opt_iter_stats>& stats,
                     std::string& err) {
-  return e->optimize(max_iters, stats, err);
+  int rc = e->optimize(max_iters, stats, err);
+  if (rc) return rc;
+  return e->check_foreign_ranges(err);
 }
 
 int engine_chi2(Engine* e, double* chi2, std::string& err) { return e->chi2(chi2, err); }
@@ -632,7 +670,7 @@ int engine_linearize(Engine* e, std::string& err) {
   int rc = e->linearize(err);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
-  return SIM3OPT_OK;
+  return e->check_foreign_ranges(err);
 }
 
 int engine_get_system(Engine* e, int32_t* rowptr, int32_t* colidx, double* values, double* b,
@@ -644,9 +682,11 @@ int engine_get_system(Engine* e, int32_t* rowptr, int32_t* colidx, double* value
   HIPCHK(hipStreamSynchronize(e->stream));
   if (rowptr) std::memcpy(rowptr, e->st.rowptr.data(), sizeof(int32_t) * (size_t)(e->nb + 1));
   if (colidx) std::memcpy(colidx, e->st.colidx.data(), sizeof(int32_t) * (size_t)e->nnzb);
-  if (values)
-    HIPCHK(hipMemcpy(values, e->d_vals, sizeof(double) * 49 * (size_t)e->nnzb,
-                     hipMemcpyDeviceToHost));
+  if (values) {  // (a partitioned run holds this rank's rows only: the other rows' blocks read zero)
+    const size_t k0 = (size_t)49 * e->st.rowptr[e->r0], k1 = (size_t)49 * e->st.rowptr[e->r1];
+    std::memset(values, 0, sizeof(double) * 49 * (size_t)e->nnzb);
+    if (k1 > k0) HIPCHK(hipMemcpy(values + k0, e->d_vals + k0, sizeof(double) * (k1 - k0), hipMemcpyDeviceToHost));
+  }
   if (b) HIPCHK(hipMemcpy(b, e->d_b, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost));
   return SIM3OPT_OK;
 }
@@ -685,6 +725,12 @@ void engine_local_rows(const Engine* e, int32_t* begin, int32_t* end) {
 int engine_preconditioner(const Engine* e) { return e->use_amg ? 2 : (e->use_chain ? 1 : 0); }
 
 int engine_linear_solver(const Engine* e) { return e->use_direct ? 1 : 0; }
+
+void engine_device_bytes(const Engine* e, int64_t bytes[2]) {
+  bytes[0] = e->ranged_bytes();
+  bytes[1] = 0;
+  for (const Engine::RangedArray& a : e->ranged) bytes[1] += (int64_t)a.elem * a.total;
+}
 
 void engine_amg_in_use(const Engine* e, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]) {
   if (n_levels) *n_levels = e->use_amg ? (int32_t)e->amg.size() : 0;

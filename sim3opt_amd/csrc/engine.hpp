@@ -42,6 +42,7 @@ int engine_bench_stream(Engine* e, int32_t mode, int32_t reps, double* ms_mean, 
 int engine_preconditioner(const Engine* e);
 int engine_linear_solver(const Engine* e);
 void engine_amg_in_use(const Engine* e, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]);
+void engine_device_bytes(const Engine* e, int64_t bytes[2]);
 int engine_kernel_times(Engine* e, sim3opt_kernel_times* out, bool reset);
 int engine_comm_times(Engine* e, sim3opt_comm_times* out);
 #ifdef SIM3OPT_BENCH_HOOKS

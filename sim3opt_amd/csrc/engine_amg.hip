@@ -119,7 +119,8 @@ int Engine::amg_bind(const Structure& s, std::string& err) {
       partition_rows(nloc, h.rowptr.data() + L.lo, L.span_grid * 4, wrow.data());
       for (int32_t& w : wrow) w += L.lo;
       AMGCHK(amg_up(L.wrow, wrow, err));
-      AMGCHK(amg_alloc(L.vals, (size_t)49 * L.nnzb, err));
+      // (a partitioned level's blocks: this rank's rows only -- alloc_ranged; replicated levels: all)
+      AMGCHK(alloc_ranged(L.vals, 49 * (int64_t)h.rowptr[L.lo], 49 * (int64_t)h.rowptr[L.hi], 49 * (int64_t)L.nnzb, err));
       AMGCHK(amg_alloc(L.diagH, (size_t)49 * L.nb, err));
       AMGCHK(amg_alloc(L.W, (size_t)49 * L.nb, err));
       AMGCHK(amg_alloc(L.Minv, (size_t)49 * L.nb, err));
@@ -128,10 +129,11 @@ int Engine::amg_bind(const Structure& s, std::string& err) {
       AMGCHK(amg_alloc(L.t, (size_t)7 * L.nb, err));
     }
     if (amg_fp32) {
-      const size_t n32 = (size_t)98 * (size_t)((std::max<int64_t>(L.nnzb, 1) + 1) / 2);  // whole pairs
-      HIPCHK(dev_malloc((void**)&L.vals32, sizeof(float) * n32));
-      HIPCHK(hipMemset(L.vals32, 0, sizeof(float) * n32));
-      amg_owned.push_back(L.vals32);
+      // whole pairs of blocks (f32_pair_index); of a partitioned level the pairs that hold this rank's rows' blocks
+      // (a span's first / last pair may reach one block into a neighbour's rows: loaded, skipped by the kernel)
+      const int64_t b0 = l == 0 ? s.rowptr[L.lo] : h.rowptr[L.lo], b1 = l == 0 ? s.rowptr[L.hi] : h.rowptr[L.hi];
+      const int64_t n32 = 98 * ((std::max<int64_t>(L.nnzb, 1) + 1) / 2);
+      AMGCHK(alloc_ranged(L.vals32, 98 * (b0 / 2), 98 * ((b1 + 1) / 2), n32, err));
     }
     if (l + 1 < nl) {
       AMGCHK(amg_up(L.agg, h.agg, err));
@@ -211,8 +213,8 @@ int Engine::amg_setup(std::string& err) {
       hipLaunchKernelGGL((k_amg_wsum<true>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem, d_P, Cc.W);
     else
       hipLaunchKernelGGL((k_amg_wsum<false>), dim3(gw), dim3(WG), 0, stream, Cc.nb, F.mptr, F.mem, F.W, Cc.W);
-    hipLaunchKernelGGL(k_amg_copydiag, dim3(grid_for(49 * (int64_t)Cc.nb, WG)), dim3(WG), 0, stream,
-                       Cc.nb, Cc.rowptr, Cc.vals, Cc.diagH);
+    hipLaunchKernelGGL(k_amg_copydiag, dim3(grid_for(49 * (int64_t)std::max(1, Cc.hi - Cc.lo), WG)), dim3(WG), 0, stream,
+                       Cc.lo, Cc.hi, Cc.rowptr, Cc.vals, Cc.diagH);
   }
   if (amg_fp32)  // (the Galerkin products wrote the FP32 copies of the levels they read)
     for (int l = nl - 1; l < nl; ++l) {

@@ -133,6 +133,40 @@ class Engine {
   int span_grid = 0;  // workgroups of the span SpMV
   int32_t *d_slot01 = nullptr, *d_slot10 = nullptr, *d_inc0 = nullptr, *d_inc1 = nullptr;
   double *d_vals = nullptr, *d_scratch = nullptr, *d_b = nullptr, *d_Minv = nullptr;
+  // Arrays indexed by a GLOBAL position (block, incidence) of which a rank touches one contiguous range -- the
+  // blocks / incidences of its own rows: H, its FP32 copy, the partitioned coarse levels, the assembly scratch --
+  // are allocated for that range only (what makes N ranks hold N times the graph): the pointer the kernels index
+  // is the virtual base `allocation - lo`; positions outside [lo, hi) are never dereferenced.
+  // options.debug_full_arrays: the whole array, everything outside the range filled with 0xFF bytes (NaN as
+  // float and as double); check_foreign_ranges() finds a write there, a read shows up as NaN in the results --
+  // the test of the ranges (tests/test_distributed_gpu.py).  One rank: lo = 0, hi = total.
+  struct RangedArray { void* alloc; size_t elem; int64_t total, lo, hi; };
+  std::vector<RangedArray> ranged;
+  template <typename T>
+  int alloc_ranged(T*& virt, int64_t lo, int64_t hi, int64_t total, std::string& err) {
+    total = std::max<int64_t>(total, 1);
+    lo = std::max<int64_t>(0, std::min(lo, total));
+    hi = std::max(lo, std::min(hi, total));
+    T* p = nullptr;
+    if (opt.debug_full_arrays) {
+      HIPCHK(dev_malloc((void**)&p, sizeof(T) * (size_t)total));
+      HIPCHK(hipMemset(p, 0xFF, sizeof(T) * (size_t)total));
+      if (hi > lo) HIPCHK(hipMemset(p + lo, 0, sizeof(T) * (size_t)(hi - lo)));
+      virt = p;
+    } else {
+      HIPCHK(dev_malloc((void**)&p, sizeof(T) * (size_t)std::max<int64_t>(hi - lo, 1)));
+      HIPCHK(hipMemset(p, 0, sizeof(T) * (size_t)std::max<int64_t>(hi - lo, 1)));
+      virt = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) - sizeof(T) * (size_t)lo);
+    }
+    ranged.push_back({p, sizeof(T), total, lo, hi});
+    return SIM3OPT_OK;
+  }
+  int check_foreign_ranges(std::string& err);  // (debug_full_arrays only; else a no-op)
+  int64_t ranged_bytes() const {               // device bytes of the ranged arrays as allocated
+    int64_t b = 0;
+    for (const RangedArray& a : ranged) b += (int64_t)a.elem * (opt.debug_full_arrays ? a.total : std::max<int64_t>(a.hi - a.lo, 1));
+    return b;
+  }
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_s = nullptr;
   double *d_part_a = nullptr, *d_part_b = nullptr;
   // chain-segment preconditioner (Sinv lives in d_Minv)

@@ -393,3 +393,12 @@ __global__ __launch_bounds__(WG) void k_scale(int j0, int j1, const double* __re
   const double s = block_sum(acc, sh);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
+
+// debug_full_arrays: 32-bit words of [p, p + nwords) that are no longer the 0xFF poison
+__global__ __launch_bounds__(WG) void k_count_unpoisoned(const uint32_t* __restrict__ p, size_t nwords,
+                                                         unsigned long long* __restrict__ count) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < nwords; i += (size_t)gridDim.x * WG)
+    c += p[i] != 0xFFFFFFFFu;
+  if (c) atomicAdd(count, c);
+}

@@ -58,6 +58,7 @@ class Options(C.Structure):
         ("amg_omega", C.c_double),
         ("amg_over", C.c_double * 2),
         ("direct_max_pairs", C.c_int64),
+        ("debug_full_arrays", C.c_int32),
     ]
 
 
@@ -166,6 +167,7 @@ SYMBOLS = {
     "sim3opt_comm_init_callbacks": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sim3opt_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
     "sim3opt_amg_in_use": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "sim3opt_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "sim3opt_halo_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, _ip, _ip, _ip]),
     "sim3opt_local_rows": (C.c_int, [_vp, _ip, _ip]),
     "sim3opt_partition_plan": (C.c_int, [_vp, C.c_int32, C.c_int32, _ip, _ip, _ip, C.POINTER(C.c_int64)]),
@@ -550,6 +552,12 @@ class Graph:
         v = np.zeros(4, dtype=np.int32)
         self._chk(self._L.sim3opt_amg_in_use(self._g, C.byref(nl), C.byref(ns), _p(v, _ip)))
         return dict(levels=nl.value, partitioned_levels=ns.value, cycle=[int(x) for x in v])
+
+    def device_bytes(self):
+        """(bytes of the block arrays as allocated on this rank, bytes one rank holding the whole graph allocates)."""
+        b = (C.c_int64 * 2)()
+        self._chk(self._L.sim3opt_device_bytes(self._g, b))
+        return int(b[0]), int(b[1])
 
     def system_pattern(self):
         """(rowptr, colidx) of the block-CSR system; host only."""

@@ -259,6 +259,59 @@ def test_many_ranks_on_small_graphs(monkeypatch, world, verts, shard):
         assert synth.rmse(r["states"], R.get_vertices()) < 2e-5
 
 
+@pytest.mark.parametrize("world,prec", [(4, 2), (3, 0), (8, 2)])
+def test_ranks_hold_and_touch_only_their_own_rows_blocks(monkeypatch, world, prec):
+    """A partitioned run allocates the block arrays (H, its FP32 copy, the partitioned coarse levels, the assembly
+    scratch) for the rank's own rows only -- N ranks hold N times the graph.  Proof of the ranges with
+    options.debug_full_arrays: whole arrays, everything outside a rank's range poisoned with NaN bytes and checked
+    after every call (a write there is an error; a read would turn the results into NaN) -- the poisoned run, the
+    trimmed run and a rank's share of the memory."""
+    from sim3opt_amd import lib as L, synth
+    monkeypatch.setenv("SIM3OPT_AMG_COARSEST", "16")
+    monkeypatch.setenv("SIM3OPT_AMG_SHARD_ROWS", "10")
+    synth.DRIFT_TARGET = 0.05
+    g = synth.manhattan(3000, 30000, dims=(15, 15, 14))
+
+    def run(debug):
+        tg = H.ThreadGroup(world)
+
+        def rank_body(rank):
+            G = L.Graph(device=0, fix_small_angle_b=1, fd_delta=1e-6, pcg_rel_tol=1e-10, preconditioner=prec,
+                        debug_full_arrays=debug)
+            G.add_vertices(g["states"], g["fixed"])
+            G.add_edges(g["v0"], g["v1"], g["meas"])
+            tg.attach(G, rank)
+            G.initialize()
+            G.linearize()   # (checked on its own: the assembly and its scratch)
+            lo, hi = G.local_rows()
+            rowptr, _, blocks, _ = G.get_system()
+            own = blocks[rowptr[lo]:rowptr[hi]]
+            n = G.optimize(5)
+            out = dict(n=n, states=G.get_vertices(), chi=[s.chi2_after for s in G.stats()], bytes=G.device_bytes(),
+                       mg=G.amg_in_use(), blocks_finite=bool(np.isfinite(own).all()),
+                       foreign_zero=bool(not blocks[:rowptr[lo]].any() and not blocks[rowptr[hi]:].any()))
+            G.close()
+            return out
+
+        return tg.run(rank_body)
+
+    poisoned = run(1)   # (an access outside a rank's range fails here, before anything is trimmed)
+    for a in poisoned:
+        assert a["n"] == 5 and a["blocks_finite"] and np.isfinite(a["states"]).all() and np.isfinite(a["chi"]).all()
+    trimmed = run(0)
+    if prec == 2:
+        assert trimmed[0]["mg"]["partitioned_levels"] >= 2
+    for a, b in zip(poisoned, trimmed):
+        assert a["n"] == b["n"] == 5 and a["blocks_finite"] and b["blocks_finite"] and b["foreign_zero"]
+        assert np.isfinite(a["states"]).all() and np.array_equal(a["states"], b["states"]) and a["chi"] == b["chi"]
+        assert np.array_equal(b["states"], trimmed[0]["states"])
+        assert a["bytes"][0] == a["bytes"][1] == b["bytes"][1]
+    total = trimmed[0]["bytes"][1]
+    shares = [r["bytes"][0] / total for r in trimmed]
+    # (level 0 by equal rows, blocks per row vary; the replicated coarse levels are whole on every rank)
+    assert max(shares) < 1.5 / world + 0.05 and abs(sum(shares) - 1.0) < 0.1 + 0.05 * world, shares
+
+
 # ------------------------------------------------------------------ config 4: the 100k / 1M graph
 def _worker_cfg3(rank, world, port, out):
     import sys
