@@ -511,7 +511,11 @@ def main():
             out["partition"] = {"row_order": "breadth-first locality order", "rows": int(nb),
                                 "boundary_rows_per_rank": [int(x) for x in bnd],
                                 "halo_fraction_of_vector": float(bnd.sum()) / max(1, int(nb)),
-                                "cut_edges": int(cut), "cut_edge_fraction": float(cut) / max(1, len(g["v0"]))}
+                                "cut_edges": int(cut), "cut_edge_fraction": float(cut) / max(1, len(g["v0"])),
+                                # block arrays (H, FP32 copy, partitioned coarse levels, assembly scratch) as
+                                # allocated on rank 0 / what one rank holding the whole graph allocates
+                                "block_array_MB_rank0": G.device_bytes()[0] / 1e6,
+                                "block_array_MB_one_rank": G.device_bytes()[1] / 1e6}
         if world == 1 and G.preconditioner_in_use() != 0 and not args.main_only:
             # same K steps with plain block-Jacobi PCG, for comparison (not part of `value`)
             J = L.Graph(device=local_rank, pcg_rel_tol=args.pcg_rel_tol, preconditioner=0,
