@@ -255,7 +255,9 @@ int sim3opt_system_dims(const sim3opt_graph* g, int32_t* n_block_rows, int64_t* 
 int sim3opt_system_pattern(sim3opt_graph* g, int32_t* n_block_rows, int64_t* n_blocks,
                            int32_t* rowptr, int32_t* colidx);
 /* copies the block-CSR Hessian (rowptr nb+1, colidx nnzb, values nnzb x 49 column-major per
- * block) and b (7 nb) to the host; block row k = k-th free vertex in insertion order */
+ * block) and b (7 nb) to the host; block row k = k-th free vertex in insertion order.  A partitioned run
+ * assembles and holds the blocks (and the entries of b) of this rank's rows only (sim3opt_local_rows): the
+ * other rows' blocks read zero */
 int sim3opt_get_system(sim3opt_graph* g, int32_t* rowptr, int32_t* colidx, double* values,
                        double* b);
 /* (a graph that is row-partitioned over several ranks numbers its block rows in locality order
