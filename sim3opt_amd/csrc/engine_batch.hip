@@ -16,7 +16,8 @@ static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
 // every batched kernel is instantiated for 2, 3 and 4 systems: a batch of three must not pay for four
 #define BATCH_DISPATCH(NS, ...) \
   do {                          \
-    if ((NS) == 2) { constexpr int KS = 2; __VA_ARGS__; } \
+    if ((NS) == 1) { constexpr int KS = 1; __VA_ARGS__; } \
+    else if ((NS) == 2) { constexpr int KS = 2; __VA_ARGS__; } \
     else if ((NS) == 3) { constexpr int KS = 3; __VA_ARGS__; } \
     else { constexpr int KS = 4; __VA_ARGS__; } \
   } while (0)
@@ -216,18 +217,23 @@ int Engine::pcg_batch(const double* lams, int nsys, int32_t* iters, double* rel_
   for (;;) {
     HIPCHK(hipMemcpyAsync(h_bsc, d_bsc, sizeof(DevScalars) * KB, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    bool all = true;
-    for (int s = 0; s < nsys; ++s) all = all && (h_bsc[s].done || h_bsc[s].stop || h_bsc[s].fail);
-    if (all || it >= max_it) break;
+    // systems still iterating: [0, live).  The dampings ascend with the trial, so the systems finish from the
+    // tail as a rule; the launches that follow carry the first `live` systems only (per system the same
+    // operations whatever K is: the results do not depend on when the others finished)
+    int live = 0;
+    for (int s = 0; s < nsys; ++s)
+      if (!(h_bsc[s].done || h_bsc[s].stop || h_bsc[s].fail)) live = s + 1;
+    if (live == 0 || it >= max_it) break;
+    b_nsys = live;
     const int todo = std::min(chunk, max_it - it);
     for (int c = 0; c < todo; ++c) {
-      BATCH_DISPATCH(nsys, hipLaunchKernelGGL((k_spmv_span<8, true, 0, double, KS, false>), dim3(gs), dim3(WG), 0, stream,
+      BATCH_DISPATCH(live, hipLaunchKernelGGL((k_spmv_span<8, true, 0, double, KS, false>), dim3(gs), dim3(WG), 0, stream,
                          nb, d_wrow, d_rowptr, d_colidx, (const double*)d_vals, (const double*)b_az, b_q, 0.0, b_part_a,
                          (const double*)nullptr, b_part_b, d_bsc, (const double*)nullptr, 1, (const int32_t*)nullptr, 1.0,
                          bs0, (const float*)nullptr));
-      BATCH_DISPATCH(nsys, hipLaunchKernelGGL((k_final_sum2_k<KS>), dim3(1), dim3(WG), 0, stream, (const double*)b_part_a,
+      BATCH_DISPATCH(live, hipLaunchKernelGGL((k_final_sum2_k<KS>), dim3(1), dim3(WG), 0, stream, (const double*)b_part_a,
                          (const double*)b_part_b, gs, SPAN_GRID_MAX, d_bsc));
-      BATCH_DISPATCH(nsys, hipLaunchKernelGGL((k_pcg_step_k<KS>), dim3(gv), dim3(WG), 0, stream, 0, nb, par, it,
+      BATCH_DISPATCH(live, hipLaunchKernelGGL((k_pcg_step_k<KS>), dim3(gv), dim3(WG), 0, stream, 0, nb, par, it,
                          (const double*)B0.Minv, (const double*)b_az, b_z, (const double*)b_q, b_p, b_s, b_x, b_r, d_bsc,
                          bs0));
       b_cycle(0, b_z, b_az);
