@@ -94,7 +94,7 @@ typedef struct sim3opt_options {
    * sim3opt_initialize (debug aid); sim3opt_get_options then reports the value that was used. ---- */
   int32_t amg_cycle[4];     /* 0,..  visits of multigrid level 1, 2, 3, >= 4 per visit of the level above
                                         (1 = V, 2 = W, 3); all 0 = automatic: {2,3,3,3}, or {1,2,2,2} when level 0
-                                        is partitioned over >= 4 ranks (the coarse cycle is what stays
+                                        is partitioned over the ranks (the coarse cycle is what stays
                                         latency-bound when level 0 is sharded)  [SIM3OPT_AMG_CYCLE] */
   int32_t amg_passes[3];    /* 0,..  pairwise-matching passes on level 0, 1, >= 2 (aggregates of 2^passes rows);
                                         0 = automatic: 3, or 2 on level 0 of a graph that reaches the dense level
@@ -115,8 +115,7 @@ typedef struct sim3opt_options {
                                         (transport self-test)                                  [SIM3OPT_FORCE_COMM] */
   int32_t amg_shard_rows;   /* 4096  partitioned runs: multigrid levels with more block rows than this are
                                         partitioned by owner like level 0 (aggregates never straddle ranks), smaller
-                                        ones are replicated; with two or three ranks the threshold is 8x this value
-                                                                                               [SIM3OPT_AMG_SHARD_ROWS] */
+                                        ones are replicated                                  [SIM3OPT_AMG_SHARD_ROWS] */
   int32_t amg_virtual_ranks;/* 0     > 1 on ONE rank: build the hierarchy as an N-rank partition would (aggregates
                                         inside N equal row spans): what a partitioned run is compared with
                                                                                                [SIM3OPT_AMG_VIRTUAL_RANKS] */
@@ -273,7 +272,7 @@ int sim3opt_preconditioner_in_use(const sim3opt_graph* g);
 int sim3opt_linear_solver_in_use(const sim3opt_graph* g);
 /* What the automatic multigrid choices resolved to on this (initialized) graph: levels of the hierarchy
  * (0: none), how many of them are partitioned over the ranks (0 on one rank), visits of levels 1, 2, 3, >= 4 per
- * visit of the level above (options.amg_cycle = 0 picks {2,3,3,3}, or {1,2,2,2} from four ranks on).  Any
+ * visit of the level above (options.amg_cycle = 0 picks {2,3,3,3}, or {1,2,2,2} on a partitioned run).  Any
  * pointer may be NULL. */
 int sim3opt_amg_in_use(const sim3opt_graph* g, int32_t* n_levels, int32_t* n_partitioned, int32_t visits[4]);
 /* Device memory of the block arrays of this (initialized) graph on this rank -- H, its FP32 copy, the coarse levels'

@@ -584,7 +584,7 @@ int sim3opt_amg_hierarchy(sim3opt_graph* g, int32_t capacity, int32_t* n_levels,
   std::vector<int32_t> vbegin;
   if (o.amg_virtual_ranks > 1) {
     bo.world = o.amg_virtual_ranks;
-    bo.shard_rows = (int32_t)std::min<int64_t>(INT32_MAX, (int64_t)std::max(1, o.amg_shard_rows) * (bo.world >= 4 ? 1 : 8));
+    bo.shard_rows = std::max(1, o.amg_shard_rows);
     vbegin.resize(bo.world + 1);
     partition_rows_equal(st.nb, bo.world, vbegin.data());
     bo.row_begin = vbegin.data();

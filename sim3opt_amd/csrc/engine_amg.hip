@@ -10,19 +10,20 @@ int Engine::amg_init(const Structure& s, bool automatic, std::string& err) {
   (void)err;
   amg_omega = std::max(0.1, std::min(0.95, opt.amg_omega));
   // cycle (measured): multiplicative on level 0; level 1 twice and deeper levels three times
-  // per visit since the cycle's matrix passes stream FP32 copies (round 2).  When level 0 is partitioned
-  // over >= 4 ranks what is left of a PCG iteration is the latency-bound coarse cycle and its exchanges:
-  // level 1 once, deeper levels twice -- half the coarse launches for about 1.5x the iterations, which
-  // loses on one GPU and wins there.  The additive level-0 form is a knob (about as fast on
-  // config 3, less robust on ill-conditioned chains).
+  // per visit since the cycle's matrix passes stream FP32 copies (round 2).  When level 0 is partitioned over
+  // the ranks what is left of a PCG iteration is the latency-bound coarse cycle and its exchanges: level 1
+  // once, deeper levels twice -- half the coarse launches and collectives for about 1.4x the iterations, which
+  // loses on one GPU and wins on every partition (at two ranks too, once the Galerkin all-gather
+  // of a replicated level 1 is counted).  The additive level-0 form is a knob (about as fast on config 3, less
+  // robust on ill-conditioned chains).
   amg_additive = opt.amg_additive != 0;
   {
-    const bool sharded4 = part_world() >= 4;
+    const bool partitioned = part_world() >= 2;
     int last = 0;
     for (int l = 1; l <= AMG_MAX_LEVELS; ++l) {
       const int o = l <= 4 ? opt.amg_cycle[l - 1] : 0;
       if (o >= 1 && o <= 3) last = o;
-      amg_visits[l] = last > 0 ? last : (sharded4 ? (l <= 1 ? 1 : 2) : (l <= 1 ? 2 : 3));
+      amg_visits[l] = last > 0 ? last : (partitioned ? (l <= 1 ? 1 : 2) : (l <= 1 ? 2 : 3));
     }
     amg_visits[0] = 1;
   }
@@ -42,7 +43,7 @@ int Engine::amg_init(const Structure& s, bool automatic, std::string& err) {
   // names): aggregates never straddle two ranks
   std::vector<int32_t> vbegin;
   bo.world = part_world();
-  bo.shard_rows = (int32_t)std::min<int64_t>(INT32_MAX, (int64_t)std::max(1, opt.amg_shard_rows) * (part_world() >= 4 ? 1 : 8));
+  bo.shard_rows = std::max(1, opt.amg_shard_rows);
   if (comm.world > 1) {
     bo.row_begin = row_begin.data();
   } else if (bo.world > 1) {
@@ -87,11 +88,10 @@ int Engine::amg_bind(const Structure& s, std::string& err) {
   // Which coarse levels are partitioned like level 0 (multi-rank runs): those with more rows than
   // options.amg_shard_rows, except the dense one -- a replicated level costs every rank its whole cycle, a
   // partitioned one costs an exchange per matrix pass; below a few thousand rows both are latency and the
-  // replicated form needs no collective.  With two or three ranks a partitioned level saves at
-  // most half / two thirds of its passes and the 2/3/3 cycle those runs keep visits level 1 twice (five more
-  // exchanges per PCG iteration): the threshold is eight times higher there (config 3's level 1, 12 k rows,
-  // stays replicated below four ranks; the model of DESIGN.md 7 gives 0.63 against 0.72 ms per iteration at N = 2)
-  const int64_t shard_rows = (int64_t)std::max(1, opt.amg_shard_rows) * (part_world() >= 4 ? 1 : 8);
+  // replicated form needs no collective.  (Round 4 first kept level 1 of config 3 replicated below
+  // four ranks -- threshold x 8 -- on a model that left out what a replicated level 1 costs per linearisation: the
+  // all-gather of its 161 MB of Galerkin blocks; with it the partitioned form wins at two ranks as well.)
+  const int64_t shard_rows = std::max(1, opt.amg_shard_rows);
   rep_level = 1;
   while (rep_level < nl - 1 && H[rep_level].nb > shard_rows && !H[rep_level].row_begin.empty() &&
          H[rep_level].respects_owner)

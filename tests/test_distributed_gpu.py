@@ -70,8 +70,7 @@ def _worker(rank, world, port, out, prec=0, neighbour=True):
                                                         (3, 2, 10, True), (4, 2, 100, True), (3, 2, 10, False)])
 def test_process_row_partition_matches_single(tmp_path, monkeypatch, world, prec, shard, neighbour):
     """prec = 2: the multigrid preconditioner on a row partition -- aggregates never straddle two ranks, so
-    Galerkin products and restrictions need no reduction; shard = 100 (10 below four ranks, where the
-    threshold counts eightfold): level 1 (167 rows) is partitioned by owner like level 0, with its own exchanges, and the first replicated level gets the owners' pieces by
+    Galerkin products and restrictions need no reduction; shard = 100 / 10: level 1 (167 rows) is partitioned by owner like level 0, with its own exchanges, and the first replicated level gets the owners' pieces by
     all-gather; neighbour = False: no alltoallv callback -- every exchange falls back to the all-gather of
     the whole vector."""
     from sim3opt_amd import lib as L, synth
@@ -414,7 +413,7 @@ def test_config4_full_size_graph_row_partitioned_over_8_ranks(monkeypatch):
         n = G.optimize(3)
         st = G.stats()
         _, _, bnd, cut = G.partition_plan(world)
-        mg = G.amg_in_use()  # the N-aware choices: levels 0-1 partitioned, cycle 1/2/2 from four ranks on
+        mg = G.amg_in_use()  # what a partitioned run chooses: levels 0-1 partitioned, cycle 1/2/2
         assert mg["levels"] == 4 and mg["partitioned_levels"] == 2 and mg["cycle"][:3] == [1, 2, 2]
         V = G.get_vertices()
         res = dict(pos=synth.positions(V), scale=V[:, 7].copy(), chi0=chi0, n=n, rows=[lo, hi],
