@@ -11,7 +11,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsim3opt.so")
+# (SIM3OPT_LIB: another build of the same library, e.g. the host-sanitizer build of scripts/host_asan_suite.sh)
+LIB_PATH = os.environ.get("SIM3OPT_LIB") or os.path.join(_HERE, "libsim3opt.so")
 # (a tuning script that A/Bs two builds sets sim3opt_amd.lib.LIB_PATH before the first load(); no
 # environment variable redirects the dlopen)
 
