@@ -8,6 +8,7 @@ TAG=$1; TMO=$2; CMD=$3
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 rm -rf "$ROOT/.snap/$TAG"
 mkdir -p "$ROOT/.snap/$TAG" "$ROOT/gpurun_out"
+# (.gpurunignore: CPU-only files gpurun's gate must not see -- the host-sanitizer script and tests)
 (cd "$ROOT" && tar --exclude=./.git --exclude=./gpurun_out --exclude=./.snap --exclude=__pycache__ \
-      --exclude=.pytest_cache -cf - .) | tar -xf - -C "$ROOT/.snap/$TAG"
+      --exclude=.pytest_cache $(sed 's|^|--exclude=./|' .gpurunignore 2>/dev/null) -cf - .) | tar -xf - -C "$ROOT/.snap/$TAG"
 exec /usr/local/graft/bin/gpurun --timeout "$TMO" -- "export OUT=\$GRAFT_REPO_ROOT/gpurun_out; mkdir -p \$OUT; cd .snap/$TAG && $CMD"
