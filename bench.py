@@ -453,6 +453,16 @@ def main():
                     if traffic is not None else None,
                     "avg_launch_ms": avg_ms, "launches": int(kt.n_spmv),
                     "algorithmic_bytes_per_launch": int(spmv_bytes)}
+            if world == 1:
+                # what THIS box delivers for a bare stream of the same block array (16 B per lane, non-temporal,
+                # after the timed region): the pool's boxes differ by up to 12 % (profiles/README.md)
+                try:
+                    sms = G.bench_stream(0, 20)
+                    sgb = 392.0 * nnzb / (sms * 1e-3) / 1e9
+                    roof["box_stream"] = {"GBs": sgb, "ms": sms, "bytes": int(392 * nnzb),
+                                          "spmv_fraction_of_box_stream": ach / sgb}
+                except Exception as ex:  # (a measurement aid, never a reason to lose the line)
+                    roof["box_stream"] = {"error": str(ex)}
         out = {
             "metric": "LM iterations/s", "value": K / dt, "unit": "LM iter/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * dt / K,
