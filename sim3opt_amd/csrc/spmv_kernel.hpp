@@ -71,6 +71,19 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
   __shared__ double sh[K][4];
   __shared__ double sh2[K][4];
   __shared__ int sh_cnt;
+  // The shared gather of the input reaches the (r, c) lanes through a wavefront-private LDS copy: one ds_write_b64 per
+  // chunk, one ds_read_b64 per block and system (seven distinct words: broadcasts, no bank conflicts) -- half the LDS
+  // instructions of the two ds_bpermute_b32 a 64-bit shuffle costs, the same values in the same order (bit-identical).
+  // End of round 4, A/B on one box: 47.2 -> 49.3 LM it/s on the driver's command, the burst iteration 136 -> 128 ms.
+  // (0: the shuffles, kept for A/B)
+#ifndef SIM3OPT_X_LDS
+#define SIM3OPT_X_LDS 1
+#endif
+  // (not for the FP64 pass over several systems: measured 260 -> 279 us for four; the one-system FP64 pass is neutral)
+  constexpr bool XLDS = SIM3OPT_X_LDS != 0 && !(sizeof(VT) == 8 && K > 1);
+  constexpr int NGX = (CH + 7) / 8;
+  __shared__ double xl[XLDS ? 4 : 1][XLDS ? K : 1][XLDS ? NGX : 1][64];
+  double (*xw)[NGX][64] = xl[XLDS ? (threadIdx.x >> 6) : 0];
   if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
     if (threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
@@ -126,16 +139,29 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
   // (every row starts with its diagonal block, so the row's own entries of p are the gather of that
   // block -- position u of the chunk in flight: a shuffle instead of one more vector-memory
   // instruction per row; the kernel is bound by the number of those, not by their bytes)
+  // entry `src` (a lane index of the shared gather) of block position u of the current chunk, system s
+  auto xget = [&](const double (*xg)[NG], int s, int u, int src) -> double {
+    if (XLDS) return xw[s][u / 8][src];
+    return __shfl(xg[s][u / 8], src);
+  };
+  auto xstage = [&](const double (*xg)[NG]) {  // (one wavefront: LDS operations complete in order, no barrier)
+    if (XLDS) {
+#pragma unroll
+      for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xw[s][g][threadIdx.x & 63] = xg[s][g];
+    }
+  };
   auto row_begin = [&](int row, int u, const double (*xg)[NG]) {
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-      pi_n[s] = __shfl(xg[s][u / 8], 7 * (u % 8) + r);
+      pi_n[s] = xget(xg, s, u, 7 * (u % 8) + r);
       if (rvec) rv_n[s] = rvec[(size_t)s * bs.vec + (size_t)7 * row + r];
       if (MODE >= 2) mv[s] = Minv[(size_t)s * bs.minv + (size_t)49 * row + l49];  // symmetric: entry (r, c49)
       // the row's own (per-system, damped) diagonal block times its own entries of the input: what the single
       // system's stream adds first (0 + d x is exact, so the row sum is bit for bit the one-system sum)
       if (DIAGK)
-        acc[s] = (double)diagk[(size_t)s * bs.diag + (size_t)49 * row + l49] * __shfl(xg[s][u / 8], 7 * (u % 8) + c49);
+        acc[s] = (double)diagk[(size_t)s * bs.diag + (size_t)49 * row + l49] * xget(xg, s, u, 7 * (u % 8) + c49);
       else
         acc[s] = 0.0;
     }
@@ -233,6 +259,7 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
     // prologue: chunk at k0
     load_chunk(k0, vc);
     gather(k0, xgc);
+    xstage(xgc);
     kfirst = kbeg;
     row_begin(row, kbeg - k0, xgc);
     for (int k = k0; k < kend; k += CH) {
@@ -272,7 +299,7 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
           for (int s = 0; s < K; ++s) {
             double xs[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xs[u] = __shfl(xgc[s][(h + u) / 8], 7 * ((h + u) % 8) + c49);
+            for (int u = 0; u < 4; ++u) xs[u] = xget(xgc, s, h + u, 7 * ((h + u) % 8) + c49);
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[s] += (double)vc[h + u] * xs[u];
           }
@@ -285,7 +312,7 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
             if (kk == k1) next_row(u);
             const double vv = DIAGK && kk == kfirst ? 0.0 : (double)vc[u];
 #pragma unroll
-            for (int s = 0; s < K; ++s) acc[s] += vv * __shfl(xgc[s][u / 8], 7 * (u % 8) + c49);
+            for (int s = 0; s < K; ++s) acc[s] += vv * xget(xgc, s, u, 7 * (u % 8) + c49);
           }
         }
       }
@@ -295,6 +322,7 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
       for (int s = 0; s < K; ++s)
 #pragma unroll
         for (int g = 0; g < NG; ++g) xgc[s][g] = xgn[s][g];
+      xstage(xgc);
     }
     row_end(row);  // last row of the span
   }
