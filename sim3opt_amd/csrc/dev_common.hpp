@@ -10,6 +10,16 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Lanes of ONE wavefront exchanging values through LDS: the hardware executes a wavefront's LDS instructions in
+// order, so no instruction is needed -- but the compiler must not move an LDS access across the hand-over (it may
+// otherwise split the lanes by a condition and let one side read before the other side wrote: seen, end of round 4),
+// and the hand-over must stay convergent.  Wavefront-scope fences + the (instruction-free) wave barrier say that.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh4) {
   v = wave_sum(v);
   __syncthreads();

@@ -84,6 +84,15 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
   constexpr int NGX = (CH + 7) / 8;
   __shared__ double xl[XLDS ? 4 : 1][XLDS ? K : 1][XLDS ? NGX : 1][64];
   double (*xw)[NGX][64] = xl[XLDS ? (threadIdx.x >> 6) : 0];
+  // ... and the row epilogue's sums over the seven columns likewise: lane (r, c) writes its term to slot 8 r + c, lane r
+  // reads its row back (three ds_read_b128 + one b64) and adds c = 0 ... 6 in that order -- the order of the six
+  // 64-bit shuffles it replaces (twelve ds_bpermute_b32), bit-identical
+#ifndef SIM3OPT_ROWEND_LDS
+#define SIM3OPT_ROWEND_LDS 1  // (0: the shuffles, kept for A/B)
+#endif
+  constexpr bool RLDS = XLDS && SIM3OPT_ROWEND_LDS != 0;
+  __shared__ __attribute__((aligned(16))) double rl[XLDS ? 4 : 1][64];
+  double* const rw = rl[XLDS ? (threadIdx.x >> 6) : 0];
   if (MODE == 2 || MODE == 0) {  // (arrival counter of the barrier-free partial sums below)
     if (threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
@@ -144,12 +153,14 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
     if (XLDS) return xw[s][u / 8][src];
     return __shfl(xg[s][u / 8], src);
   };
-  auto xstage = [&](const double (*xg)[NG]) {  // (one wavefront: LDS operations complete in order, no barrier)
+  auto xstage = [&](const double (*xg)[NG]) {  // (one wavefront: wave_lds_sync, no workgroup barrier)
     if (XLDS) {
+      wave_lds_sync();  // (the reads of the previous chunk are done)
 #pragma unroll
       for (int s = 0; s < K; ++s)
 #pragma unroll
         for (int g = 0; g < NG; ++g) xw[s][g][threadIdx.x & 63] = xg[s][g];
+      wave_lds_sync();
     }
   };
   auto row_begin = [&](int row, int u, const double (*xg)[NG]) {
@@ -168,12 +179,26 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
   };
   // a block row is complete: reduce its 7 columns, add the damping, apply the epilogue
   // (row sums are valid in lanes 0..6)
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  auto colsum = [&](double v) -> double {  // sum over c of the terms of lanes (r, c); valid in lanes 0..6
+    if (RLDS) {
+      wave_lds_sync();
+      rw[8 * r + c49] = v;
+      wave_lds_sync();
+      const d2_t* pp = reinterpret_cast<const d2_t*>(rw + 8 * (lane < 7 ? lane : 0));
+      const d2_t a = pp[0], b = pp[1], c = pp[2];
+      const double e = rw[8 * (lane < 7 ? lane : 0) + 6];
+      return (((((a.x + a.y) + b.x) + b.y) + c.x) + c.y) + e;
+    }
+    double y = v;
+#pragma unroll
+    for (int cc = 1; cc < 7; ++cc) y += __shfl(v, r + 7 * cc);
+    return y;
+  };
   auto row_end = [&](int row) {
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-      double y = acc[s];
-#pragma unroll
-      for (int cc = 1; cc < 7; ++cc) y += __shfl(acc[s], r + 7 * cc);
+      double y = colsum(acc[s]);
       const double pi = pi_n[s];
       y += lam[s] * pi;
       double* qs = q + (size_t)s * bs.vec;
@@ -188,10 +213,16 @@ void k_spmv_span(int nb, const int32_t* __restrict__ wrow,
         if (MODE == 1) {
           if (lane < 7) qs[(size_t)7 * row + lane] = d;
         } else {
-          const double pr_ = mv[s] * __shfl(d, c49);  // Minv(r, c) d_c
-          double o = pr_;
-#pragma unroll
-          for (int cc = 1; cc < 7; ++cc) o += __shfl(pr_, r + 7 * cc);
+          double dc;  // d_c for lane (r, c)
+          if (RLDS) {
+            if (lane < 7) rw[56 + lane] = d;
+            wave_lds_sync();
+            dc = rw[56 + c49];
+          } else {
+            dc = __shfl(d, c49);
+          }
+          const double pr_ = mv[s] * dc;  // Minv(r, c) d_c
+          const double o = colsum(pr_);
           if (lane < 7) {
             const double zo = pi + o;
             qs[(size_t)7 * row + lane] = zo;
