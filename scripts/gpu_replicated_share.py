@@ -31,6 +31,7 @@ o = G.options()
 out = dict(virtual_ranks=N, vertices=V, edges=E, lm_iters=int(n), pcg_iters=[int(s.pcg_iters) for s in st],
            levels_rows=[int(x) for x in rows], levels_blocks=[int(x) for x in blocks], amg_cycle_option=list(o.amg_cycle),
            amg_shard_rows=int(o.amg_shard_rows),
+           ms_solve=[float(s.ms_solve) for s in st],
            ms_solve_per_pcg_iteration=float(sum(s.ms_solve for s in st)) / max(1, npcg),
            ms_replicated_levels_per_pcg_iteration=kt.ms_replicated_levels / max(1, npcg),
            replicated_visits_per_pcg_iteration=kt.n_replicated_visits / max(1, npcg),
