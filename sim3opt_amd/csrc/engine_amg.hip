@@ -298,7 +298,7 @@ hipLaunchKernelGGL((k_spmv_span<8, NTV, MODEV>), dim3(L.span_grid), dim3(WG), 0,
                    const_cast<double*>(xc), level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1,   \
                    (const int32_t*)L.agg, amg_over, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)
 #define AMG_SPMV32(NTV, MODEV)                                                                    \
-hipLaunchKernelGGL((k_spmv_span<(NTV) ? SIM3OPT_F32_CH : 8, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
+hipLaunchKernelGGL((k_spmv_span<(NTV) ? SIM3OPT_F32_CH : SIM3OPT_COARSE_CH, NTV, MODEV, float>), dim3(L.span_grid), dim3(WG), 0, stream,  \
                    L.nb, L.wrow, L.rowptr, L.colidx, (const float*)L.vals32, v, out, 0.0,         \
                    rz_part, rvec, const_cast<double*>(xc),                                        \
                    level == 0 ? d_sc : (DevScalars*)nullptr, L.Minv, 1, (const int32_t*)L.agg, amg_over, BatchStrides{0, 0, 0, 0, 0}, (const float*)nullptr)

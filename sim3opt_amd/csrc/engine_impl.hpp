@@ -61,6 +61,9 @@ using sim3::Sim3;
     }                                                                       \
   } while (0)
 
+#ifndef SIM3OPT_COARSE_CH
+#define SIM3OPT_COARSE_CH 8     // blocks per pipeline step of the coarse levels' passes (one-system cycle; tuning: 16)
+#endif
 #ifndef SIM3OPT_F32_CH
 #define SIM3OPT_F32_CH 8        // blocks per pipeline step of the level-0 FP32 passes (tuning: 16)
 #endif
