@@ -465,6 +465,30 @@ def main():
                                           "spmv_fraction_of_best_stream": ach / max(sgb.values())}
                 except Exception as ex:  # (a measurement aid, never a reason to lose the line)
                     roof["box_stream"] = {"error": str(ex)}
+                # ... and its clocks while the SpMV runs back to back for ~2 s (rocm-smi from a thread; the pool's slow
+                # boxes stream as fast as the fast ones but run this kernel 12 % slower)
+                try:
+                    import re, subprocess, threading
+                    smi = {}
+
+                    def _smi():
+                        time.sleep(0.6)
+                        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20)
+                        for key in ("sclk", "mclk", "fclk"):
+                            m = re.search(key + r" clock level: \S+ \((\d+)Mhz\)", r.stdout)
+                            if m:
+                                smi[key + "_mhz_under_load"] = int(m.group(1))
+                        m = re.search(r"Power \(W\): ([0-9.]+)", r.stdout)
+                        if m:
+                            smi["power_w_under_load"] = float(m.group(1))
+
+                    th = threading.Thread(target=_smi)
+                    th.start()
+                    G.bench_spmv(int(2.5 / max(avg_ms * 1e-3, 1e-5)))
+                    th.join()
+                    roof["box_clocks"] = smi
+                except Exception as ex:
+                    roof["box_clocks"] = {"error": str(ex)}
         out = {
             "metric": "LM iterations/s", "value": K / dt, "unit": "LM iter/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * dt / K,
